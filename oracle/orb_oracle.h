@@ -1,0 +1,99 @@
+/*
+ * orb_oracle.h -- C interface of the CPU ORACLE for the ORB front end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under orb_slam2_amd/ may include, link or
+ * call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (abhineet123/ORB_SLAM2) ships no tests,
+ * fixtures or golden vectors and its arithmetic lives in
+ * OpenCV, which is neither vendored nor installed here, so the reference
+ * cannot be compiled (oracle/_ref is therefore absent).  This oracle restates
+ * src/ORBextractor.cc, src/ORBmatcher.cc:1647-1663 and src/Frame.cc:466-640
+ * line by line together with the generic C++ path of OpenCV 2.4.11/3.2 for
+ * resize / FAST / GaussianBlur / fastAtan2, and is
+ * checked against hand-derivable known answers in tests/test_oracle_kat.py.
+ */
+#ifndef ORB_ORACLE_H_
+#define ORB_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout of cv::KeyPoint (7 x 4 bytes) */
+typedef struct orc_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct orc_extractor orc_extractor;
+
+/* ---- ORBextractor (src/ORBextractor.cc:410-470, 1043-1105) ---- */
+orc_extractor *orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast);
+void orc_destroy(orc_extractor *e);
+/* operator(): returns 0, *n_out = number of keypoints (<= cap or -1 if cap too small) */
+int orc_extract(orc_extractor *e, const uint8_t *img, int w, int h, int stride,
+                orc_keypoint *kps, int cap, uint8_t *desc32, int *n_out);
+
+/* constructor tables */
+int orc_nlevels(const orc_extractor *e);
+void orc_scale_tables(const orc_extractor *e, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2);
+void orc_features_per_level(const orc_extractor *e, int *out);
+void orc_umax(const orc_extractor *e, int *out16);
+
+/* state left behind by the last orc_extract (introspection for stage-wise parity) */
+int orc_level_size(const orc_extractor *e, int level, int *w, int *h);
+const uint8_t *orc_level_ptr(const orc_extractor *e, int level);   /* w*h, contiguous (the ROI, no border) */
+const uint8_t *orc_blur_ptr(const orc_extractor *e, int level);    /* w*h or NULL if level had 0 keypoints */
+/* FAST candidates of a level in reference order; x,y relative to minBorder (16); 3 floats each (x,y,response) */
+int orc_level_candidates(const orc_extractor *e, int level, float *xyr, int cap);
+/* keypoints kept by DistributeOctTree for a level, list order, level coordinates incl. border; 4 floats (x,y,response,angle) */
+int orc_level_selected(const orc_extractor *e, int level, float *xyra, int cap);
+
+/* ---- stand-alone primitives ---- */
+/* cv::resize(..., INTER_LINEAR) 8UC1, OpenCV 2.4/3.2 generic path */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh, int dstride);
+/* coefficient tables of that resize: xofs[dw], ialpha[2*dw] (also for y with dh) */
+void orc_resize_tables(int ssize, int dsize, int *ofs, int16_t *coef);
+/* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) 8UC1 pre-3.4.1 fixed-point path */
+void orc_gauss7_u8(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+void orc_gauss7_kernel(int *k7);
+/* cv::FAST(win, kps, threshold, true) (TYPE_9_16); returns count; xyr = (x,y,response) window coords */
+int orc_fast9(const uint8_t *win, int w, int h, int stride, int threshold, float *xyr, int cap);
+/* the per-level cell loop of ComputeKeyPointsOctTree (src/ORBextractor.cc:771-829) */
+int orc_fast_cells(const uint8_t *img, int w, int h, int stride, int ini_th, int min_th, float *xyr, int cap);
+float orc_fast_atan2(float y, float x);
+float orc_ic_angle(const uint8_t *img, int stride, int cx, int cy, const int *umax16);
+void orc_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float angle_deg, uint8_t *desc32);
+/* DistributeOctTree (src/ORBextractor.cc:539-763); xyr in/out 3 floats each; returns kept count */
+int orc_distribute_octree(const float *xyr, int n, int minX, int maxX, int minY, int maxY, int N, float *out_xyr, int cap);
+int orc_cv_round(double v);
+
+/* ---- ORBmatcher (src/ORBmatcher.cc:1647-1663) ---- */
+int orc_hamming(const uint8_t *a32, const uint8_t *b32);
+/* brute-force best / second-best (update rule of src/ORBmatcher.cc:216-225); idx = -1 if nr == 0 */
+void orc_knn2(const uint8_t *q, int nq, const uint8_t *r, int nr, int32_t *best_dist, int32_t *best_idx, int32_t *second_dist);
+/* candidate-list form: for query i the candidates are cand_idx[cand_off[i] .. cand_off[i+1]) */
+void orc_match_csr(const uint8_t *q, int nq, const uint8_t *r, const int32_t *cand_off, const int32_t *cand_idx,
+                   int32_t *best_dist, int32_t *best_idx, int32_t *second_dist);
+
+/* ---- Frame::ComputeStereoMatches (src/Frame.cc:466-640) ---- */
+/* Hamming row-band search only (src/Frame.cc:476-549): best_dist[iL] (TH_HIGH=100 if none), best_idx[iL] */
+void orc_stereo_rowband(const orc_keypoint *kl, const uint8_t *dl, int nl, const orc_keypoint *kr, const uint8_t *dr, int nr,
+                        const float *scale_factors, int nrows, float min_d, float max_d, int32_t *best_dist, int32_t *best_idx);
+/* the whole routine incl. SAD refinement, parabola, median gate: u_right[nl], depth[nl] */
+void orc_stereo_full(const orc_extractor *el, const orc_extractor *er, const orc_keypoint *kl, const uint8_t *dl, int nl,
+                     const orc_keypoint *kr, const uint8_t *dr, int nr, float bf, float b, float *u_right, float *depth);
+
+/* time n_frames calls of orc_extract over `threads` threads (one frame per thread at a time); returns seconds */
+double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
+                        int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps);
+double orc_time_knn2(const uint8_t *q, int nq, const uint8_t *r, int nr, int threads, int swar);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

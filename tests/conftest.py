@@ -1,0 +1,25 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kitti_frame():
+    from orb_slam2_amd import synth
+    return synth.textured_image(1241, 376, synth.BASE_SEED)
+
+
+@pytest.fixture(scope="session")
+def tum_frame():
+    from orb_slam2_amd import synth
+    return synth.textured_image(640, 480, synth.BASE_SEED + 1)

@@ -1,0 +1,272 @@
+"""ctypes binding of oracle/liborb_oracle.so (TEST INFRASTRUCTURE: the checker, never the product path)."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+i16p = C.POINTER(C.c_int16)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = ROOT / "oracle" / "liborb_oracle.so"
+        if not so.exists():
+            subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
+        L = C.CDLL(str(so))
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_extract.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, u8p, i32p]
+        L.orc_nlevels.argtypes = [C.c_void_p]
+        L.orc_scale_tables.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p]
+        L.orc_features_per_level.argtypes = [C.c_void_p, i32p]
+        L.orc_umax.argtypes = [C.c_void_p, i32p]
+        L.orc_level_size.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.orc_level_ptr.restype = C.c_void_p
+        L.orc_level_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.orc_blur_ptr.restype = C.c_void_p
+        L.orc_blur_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int]
+        L.orc_level_selected.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+        L.orc_resize_tables.argtypes = [C.c_int, C.c_int, i32p, i16p]
+        L.orc_gauss7_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+        L.orc_gauss7_kernel.argtypes = [i32p]
+        L.orc_fast9.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
+        L.orc_fast_cells.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p]
+        L.orc_descriptor.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float, u8p]
+        L.orc_distribute_octree.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
+        L.orc_cv_round.argtypes = [C.c_double]
+        L.orc_hamming.argtypes = [u8p, u8p]
+        L.orc_knn2.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p, i32p]
+        L.orc_match_csr.argtypes = [u8p, C.c_int, u8p, i32p, i32p, i32p, i32p, i32p]
+        L.orc_stereo_rowband.argtypes = [C.c_void_p, u8p, C.c_int, C.c_void_p, u8p, C.c_int, f32p, C.c_int, C.c_float,
+                                         C.c_float, i32p, i32p]
+        L.orc_stereo_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u8p, C.c_int, C.c_void_p, u8p, C.c_int,
+                                      C.c_float, C.c_float, f32p, f32p]
+        L.orc_time_extract.restype = C.c_double
+        L.orc_time_extract.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long)]
+        L.orc_time_knn2.restype = C.c_double
+        L.orc_time_knn2.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+class OracleExtractor:
+    """Mirror of ORB_SLAM2::ORBextractor on the oracle."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.h = self.L.orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        out = [np.zeros(n, np.float32) for _ in range(4)]
+        self.L.orc_scale_tables(self.h, *[_ptr(o, f32p) for o in out])
+        fpl = np.zeros(n, np.int32)
+        self.L.orc_features_per_level(self.h, _ptr(fpl, i32p))
+        um = np.zeros(16, np.int32)
+        self.L.orc_umax(self.h, _ptr(um, i32p))
+        return dict(scale=out[0], inv_scale=out[1], sigma2=out[2], inv_sigma2=out[3], features_per_level=fpl, umax=um)
+
+    def extract(self, img: np.ndarray):
+        assert img.dtype == np.uint8 and img.ndim == 2
+        img = np.ascontiguousarray(img)
+        cap = self.nfeatures * 2 + 256
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        rc = self.L.orc_extract(self.h, _ptr(img, u8p), img.shape[1], img.shape[0], img.strides[0],
+                                kps.ctypes.data_as(C.c_void_p), cap, _ptr(desc, u8p), C.byref(n))
+        assert rc == 0, rc
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level(self, lvl):
+        w, h = C.c_int32(), C.c_int32()
+        assert self.L.orc_level_size(self.h, lvl, C.byref(w), C.byref(h)) == 0
+        p = self.L.orc_level_ptr(self.h, lvl)
+        return np.ctypeslib.as_array(C.cast(p, u8p), shape=(h.value, w.value)).copy()
+
+    def blurred(self, lvl):
+        w, h = C.c_int32(), C.c_int32()
+        assert self.L.orc_level_size(self.h, lvl, C.byref(w), C.byref(h)) == 0
+        p = self.L.orc_blur_ptr(self.h, lvl)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, u8p), shape=(h.value, w.value)).copy()
+
+    def candidates(self, lvl):
+        n = self.L.orc_level_candidates(self.h, lvl, None, 0)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self.L.orc_level_candidates(self.h, lvl, _ptr(out, f32p), n)
+        return out[:n]
+
+    def selected(self, lvl):
+        n = self.L.orc_level_selected(self.h, lvl, None, 0)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        self.L.orc_level_selected(self.h, lvl, _ptr(out, f32p), n)
+        return out[:n]
+
+
+def resize(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_ptr(src, u8p), src.shape[1], src.shape[0], src.strides[0], _ptr(dst, u8p), dw, dh, dw)
+    return dst
+
+
+def resize_tables(ssize: int, dsize: int):
+    ofs = np.zeros(dsize, np.int32)
+    coef = np.zeros((dsize, 2), np.int16)
+    lib().orc_resize_tables(ssize, dsize, _ptr(ofs, i32p), _ptr(coef, i16p))
+    return ofs, coef
+
+
+def gauss7(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src)
+    dst = np.zeros_like(src)
+    lib().orc_gauss7_u8(_ptr(src, u8p), src.shape[1], src.shape[0], src.strides[0], _ptr(dst, u8p), dst.strides[0])
+    return dst
+
+
+def gauss7_kernel():
+    k = np.zeros(7, np.int32)
+    lib().orc_gauss7_kernel(_ptr(k, i32p))
+    return k
+
+
+def fast9(win: np.ndarray, threshold: int) -> np.ndarray:
+    win = np.ascontiguousarray(win)
+    cap = win.size
+    out = np.zeros((max(cap, 1), 3), np.float32)
+    n = lib().orc_fast9(_ptr(win, u8p), win.shape[1], win.shape[0], win.strides[0], threshold, _ptr(out, f32p), cap)
+    return out[:n]
+
+
+def fast_cells(img: np.ndarray, ini_th=20, min_th=7) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    cap = img.size // 4 + 16
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().orc_fast_cells(_ptr(img, u8p), img.shape[1], img.shape[0], img.strides[0], ini_th, min_th,
+                             _ptr(out, f32p), cap)
+    assert n <= cap
+    return out[:n]
+
+
+def fast_atan2(y, x) -> float:
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def ic_angle(img: np.ndarray, cx: int, cy: int, umax: np.ndarray) -> float:
+    img = np.ascontiguousarray(img)
+    umax = np.ascontiguousarray(umax, np.int32)
+    return float(lib().orc_ic_angle(_ptr(img, u8p), img.strides[0], cx, cy, _ptr(umax, i32p)))
+
+
+def descriptor(blurred: np.ndarray, cx: int, cy: int, angle_deg: float) -> np.ndarray:
+    blurred = np.ascontiguousarray(blurred)
+    d = np.zeros(32, np.uint8)
+    lib().orc_descriptor(_ptr(blurred, u8p), blurred.strides[0], cx, cy, float(angle_deg), _ptr(d, u8p))
+    return d
+
+
+def distribute_octree(xyr: np.ndarray, minX, maxX, minY, maxY, N) -> np.ndarray:
+    xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+    cap = len(xyr) + 8
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().orc_distribute_octree(_ptr(xyr, f32p), len(xyr), minX, maxX, minY, maxY, N, _ptr(out, f32p), cap)
+    return out[:n]
+
+
+def hamming(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().orc_hamming(_ptr(a, u8p), _ptr(b, u8p)))
+
+
+def knn2(q: np.ndarray, r: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8)
+    r = np.ascontiguousarray(r, np.uint8)
+    nq, nr = len(q), len(r)
+    bd, bi, sd = (np.zeros(nq, np.int32) for _ in range(3))
+    lib().orc_knn2(_ptr(q, u8p), nq, _ptr(r, u8p), nr, _ptr(bd, i32p), _ptr(bi, i32p), _ptr(sd, i32p))
+    return bd, bi, sd
+
+
+def match_csr(q: np.ndarray, r: np.ndarray, off: np.ndarray, idx: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8)
+    r = np.ascontiguousarray(r, np.uint8)
+    off = np.ascontiguousarray(off, np.int32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    nq = len(q)
+    bd, bi, sd = (np.zeros(nq, np.int32) for _ in range(3))
+    lib().orc_match_csr(_ptr(q, u8p), nq, _ptr(r, u8p), _ptr(off, i32p), _ptr(idx, i32p), _ptr(bd, i32p), _ptr(bi, i32p),
+                        _ptr(sd, i32p))
+    return bd, bi, sd
+
+
+def stereo_rowband(kl, dl, kr, dr, scale_factors, nrows, min_d, max_d):
+    kl = np.ascontiguousarray(kl)
+    kr = np.ascontiguousarray(kr)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    bd, bi = np.zeros(len(kl), np.int32), np.zeros(len(kl), np.int32)
+    lib().orc_stereo_rowband(kl.ctypes.data_as(C.c_void_p), _ptr(dl, u8p), len(kl), kr.ctypes.data_as(C.c_void_p),
+                             _ptr(dr, u8p), len(kr), _ptr(sf, f32p), nrows, min_d, max_d, _ptr(bd, i32p), _ptr(bi, i32p))
+    return bd, bi
+
+
+def stereo_full(el: OracleExtractor, er: OracleExtractor, kl, dl, kr, dr, bf, b):
+    kl = np.ascontiguousarray(kl)
+    kr = np.ascontiguousarray(kr)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    ur, dep = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32)
+    lib().orc_stereo_full(el.h, er.h, kl.ctypes.data_as(C.c_void_p), _ptr(dl, u8p), len(kl),
+                          kr.ctypes.data_as(C.c_void_p), _ptr(dr, u8p), len(kr), bf, b, _ptr(ur, f32p), _ptr(dep, f32p))
+    return ur, dep
+
+
+def time_extract(frames: np.ndarray, nfeatures, scale_factor, nlevels, ini_th, min_th, threads, reps=1):
+    frames = np.ascontiguousarray(frames)
+    n, h, w = frames.shape
+    tot = C.c_long(0)
+    t = lib().orc_time_extract(nfeatures, scale_factor, nlevels, ini_th, min_th, _ptr(frames, u8p), n, w, h, w, w * h,
+                               threads, reps, C.byref(tot))
+    return t, tot.value
+
+
+def time_knn2(q, r, threads, swar=False):
+    q = np.ascontiguousarray(q, np.uint8)
+    r = np.ascontiguousarray(r, np.uint8)
+    return lib().orc_time_knn2(_ptr(q, u8p), len(q), _ptr(r, u8p), len(r), threads, 1 if swar else 0)

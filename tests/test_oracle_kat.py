@@ -1,0 +1,443 @@
+"""Known-answer tests that pin the ORACLE (oracle/orb_oracle.cpp).
+
+The reference ships no tests or golden vectors, so these are the hand-derivable
+known answers of SURVEY.md section 8c plus independent numpy restatements of the OpenCV primitives
+(written from the spec in SURVEY.md Appendix A, not from the oracle's C++).
+"""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from orb_slam2_amd import synth
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+# ---------------------------------------------------------------- (1) constructor constants
+def test_scale_tables_and_quotas():
+    t = O.OracleExtractor(2000, 1.2, 8, 20, 7).tables()
+    exp = [1, 1.2000000477, 1.4400000572, 1.7280001640, 2.0736002922, 2.4883203506, 2.9859845638, 3.5831816196]
+    assert np.array_equal(t["scale"], np.array(exp, np.float32))
+    assert list(t["features_per_level"]) == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert list(t["umax"]) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert sum(2 * u + 1 for u in t["umax"][1:]) * 2 + 31 == 749
+    assert list(O.OracleExtractor(1000, 1.2, 8, 20, 7).tables()["features_per_level"]) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(O.OracleExtractor(1200, 1.2, 8, 20, 7).tables()["features_per_level"]) == [261, 217, 181, 151, 126, 105, 87, 72]
+
+
+@pytest.mark.parametrize("wh,sizes", [
+    ((1241, 376), [(1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]),
+    ((640, 480), [(533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]),
+    ((752, 480), [(627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]),
+])
+def test_level_sizes(wh, sizes):
+    e = O.OracleExtractor(500, 1.2, 8, 20, 7)
+    e.extract(np.zeros((wh[1], wh[0]), np.uint8))
+    got = [e.level(l).shape[::-1] for l in range(1, 8)]
+    assert got == sizes
+
+
+def test_cv_round_half_even():
+    L = O.lib()
+    assert [L.orc_cv_round(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+# ---------------------------------------------------------------- (2) fastAtan2
+def test_fast_atan2_axes():
+    assert O.fast_atan2(0, 0) == 0.0
+    assert O.fast_atan2(0, 1) == 0.0
+    assert O.fast_atan2(1, 0) == 90.0
+    assert O.fast_atan2(0, -1) == 180.0
+    assert O.fast_atan2(-1, 0) == 270.0
+    for ang in np.linspace(0.5, 359.5, 97):
+        a = O.fast_atan2(math.sin(math.radians(ang)) * 1000, math.cos(math.radians(ang)) * 1000)
+        assert abs(a - ang) < 0.3  # polynomial error bound of cv::fastAtan2
+    assert abs(O.fast_atan2(5, 5) - 45) < 0.3 and abs(O.fast_atan2(-5, 5) - 315) < 0.3
+
+
+def test_fast_atan2_numpy_float32():
+    """Same polynomial evaluated with numpy float32 scalar ops (no FMA) must agree bit for bit."""
+    f = np.float32
+    k = f(180 / math.pi)
+    p1, p3, p5, p7 = (f(0.9997878412794807) * k, f(-0.3258083974640975) * k, f(0.1555786518463281) * k,
+                      f(-0.04432655554792128) * k)
+    eps = f(2.220446049250313e-16)
+    rng = np.random.default_rng(7)
+    for _ in range(2000):
+        y, x = f(rng.integers(-2800000, 2800000)), f(rng.integers(-2800000, 2800000))
+        ax, ay = abs(x), abs(y)
+        if ax >= ay:
+            c = ay / (ax + eps)
+            c2 = c * c
+            a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+        else:
+            c = ax / (ay + eps)
+            c2 = c * c
+            a = f(90) - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+        if x < 0:
+            a = f(180) - a
+        if y < 0:
+            a = f(360) - a
+        assert f(O.fast_atan2(y, x)) == a
+
+
+# ---------------------------------------------------------------- (3) FAST
+def _blank(v=100, n=15):
+    return np.full((n, n), v, np.uint8)
+
+
+def _arc(img, cx, cy, start, length, val):
+    for k in range(start, start + length):
+        dx, dy = RING[k % 16]
+        img[cy + dy, cx + dx] = val
+
+
+def np_fast_score(img):
+    """Closed form of SURVEY 8a-3: s(p) = max over the 16 nine-arcs of max(min(v - ring), min(ring - v))."""
+    h, w = img.shape
+    im = img.astype(np.int32)
+    S = np.zeros((h, w), np.int32)
+    v = im[3:h - 3, 3:w - 3]
+    ring = np.stack([im[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in RING])  # [16, h-6, w-6]
+    d = v[None] - ring
+    best = np.full(v.shape, -10**6, np.int32)
+    for a in range(16):
+        idx = [(a + i) % 16 for i in range(9)]
+        best = np.maximum(best, np.maximum(d[idx].min(0), (-d[idx]).min(0)))
+    S[3:h - 3, 3:w - 3] = best
+    return S
+
+
+def np_fast9(img, t):
+    """FAST-9/16 + strict 3x3 NMS from the closed form; emits (x, y, s-1) in row-major order."""
+    h, w = img.shape
+    if h < 7 or w < 7:
+        return np.zeros((0, 3), np.float32)
+    S = np_fast_score(img)
+    sc = np.where(S > t, S - 1, 0)
+    sc[:3] = 0; sc[h - 3:] = 0; sc[:, :3] = 0; sc[:, w - 3:] = 0
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = sc[y, x]
+            if s <= 0 or S[y, x] <= t:
+                continue
+            nb = sc[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if (s > nb).all():
+                out.append((x, y, s))
+    return np.array(out, np.float32).reshape(-1, 3)
+
+
+def test_fast_bright_dot():
+    img = _blank(100)
+    img[7, 7] = 180  # all 16 ring pixels darker by 80 -> score 80, response 79
+    r = O.fast9(img, 20)
+    assert r.tolist() == [[7.0, 7.0, 79.0]]
+
+
+def test_fast_9arc_fires_8arc_does_not():
+    for start in range(16):
+        img = _blank(100)
+        _arc(img, 7, 7, start, 9, 160)
+        r = O.fast9(img, 20)
+        assert [7.0, 7.0, 59.0] in r.tolist(), (start, r)
+        img = _blank(100)
+        _arc(img, 7, 7, start, 8, 160)
+        r = O.fast9(img, 20)
+        assert not any(p[0] == 7 and p[1] == 7 for p in r.tolist()), (start, r)
+
+
+def test_fast_threshold_edge():
+    img = _blank(100)
+    _arc(img, 7, 7, 3, 9, 121)  # ring - v = 21 > 20 -> corner, response 20
+    assert [7.0, 7.0, 20.0] in O.fast9(img, 20).tolist()
+    img = _blank(100)
+    _arc(img, 7, 7, 3, 9, 120)  # == threshold: strict compare fails
+    assert not any(p[0] == 7 and p[1] == 7 for p in O.fast9(img, 20).tolist())
+    assert [7.0, 7.0, 19.0] in O.fast9(img, 7).tolist()
+
+
+def test_fast_matches_closed_form_random():
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        h, w = rng.integers(7, 48), rng.integers(7, 48)
+        base = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        if trial % 3 == 0:  # smoother texture: plateaus and near-threshold contrasts
+            base = (base // 32 * 32).astype(np.uint8)
+        elif trial % 3 == 1:
+            base = np.clip(100 + (base.astype(int) - 128) // 6, 0, 255).astype(np.uint8)
+        for t in (7, 20):
+            a, b = O.fast9(base, t), np_fast9(base, t)
+            assert a.shape == b.shape and np.array_equal(a, b), (trial, t)
+
+
+def test_fast_plateau_suppresses_itself():
+    """Two adjacent equal-score corners: strict '>' NMS removes both (SURVEY 8a-3 note on 'empty' cells)."""
+    img = synth.textured_image(64, 64, 99)
+    r20 = O.fast9(img, 20)
+    S = np_fast_score(img)
+    n_corners = int((S[3:-3, 3:-3] > 20).sum())
+    assert n_corners >= len(r20)
+
+
+def test_fast_cells_fallback_and_border_nms():
+    # image where one cell region has only low-contrast (10) corners -> that cell must use minTh=7
+    img = np.full((120, 200), 100, np.uint8)
+    img[30, 150] = 200                   # strong dot far right (a corner at th=20)
+    img[40, 30] = 112                    # weak dot on the left (only visible at th=7)
+    c = O.fast_cells(img, 20, 7)
+    xs = c[:, 0] + 16
+    assert (xs < 60).any() and (xs > 140).any()
+    weak = c[xs < 60]
+    assert (weak[:, 2] < 20).all()
+    # with minTh == iniTh the weak blob disappears
+    c2 = O.fast_cells(img, 20, 20)
+    assert not ((c2[:, 0] + 16) < 60).any()
+
+
+def np_fast_cells(img, ini_th, min_th):
+    """Cell loop of src/ORBextractor.cc:771-829 on top of np_fast9 (independent restatement)."""
+    h, w = img.shape
+    minB, maxBX, maxBY = 16, w - 16, h - 16
+    width, height = np.float32(maxBX - minB), np.float32(maxBY - minB)
+    nCols, nRows = int(width / np.float32(30)), int(height / np.float32(30))
+    wCell, hCell = int(math.ceil(width / nCols)), int(math.ceil(height / nRows))
+    out = []
+    for i in range(nRows):
+        iniY = minB + i * hCell
+        maxY = min(iniY + hCell + 6, maxBY)
+        if iniY >= maxBY - 3:
+            continue
+        for j in range(nCols):
+            iniX = minB + j * wCell
+            maxX = min(iniX + wCell + 6, maxBX)
+            if iniX >= maxBX - 6:
+                continue
+            win = img[iniY:maxY, iniX:maxX]
+            r = np_fast9(win, ini_th)
+            if len(r) == 0:
+                r = np_fast9(win, min_th)
+            for x, y, s in r:
+                out.append((x + j * wCell, y + i * hCell, s))
+    return np.array(out, np.float32).reshape(-1, 3)
+
+
+def test_fast_cells_vs_numpy():
+    img = synth.textured_image(190, 130, 5)
+    a, b = O.fast_cells(img, 20, 7), np_fast_cells(img, 20, 7)
+    assert len(a) > 50 and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- (4) resize
+def np_resize(src, dw, dh):
+    """cv::resize INTER_LINEAR 8UC1, OpenCV 2.4/3.2 generic path, numpy restatement."""
+    sh, sw = src.shape
+
+    def tables(ssize, dsize, clamp):
+        scale = np.float64(1.0) / (np.float64(dsize) / np.float64(ssize))
+        d = np.arange(dsize, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        if clamp:
+            f = np.where(s < 0, np.float32(0), f); s = np.maximum(s, 0)
+            f = np.where(s >= ssize - 1, np.float32(0), f); s = np.minimum(s, ssize - 1)
+        c0 = np.clip(np.rint((np.float32(1) - f) * np.float32(2048)), -32768, 32767).astype(np.int64)
+        c1 = np.clip(np.rint(f * np.float32(2048)), -32768, 32767).astype(np.int64)
+        return s, c0, c1
+
+    sx, a0, a1 = tables(sw, dw, True)
+    sy, b0, b1 = tables(sh, dh, False)
+    S = src.astype(np.int64)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    H = S[:, sx] * a0[None] + np.where((sx + 1 < sw)[None], S[:, sx1] * a1[None], 0)
+    H = np.where((sx + 1 < sw)[None], H, S[:, sx] * 2048)
+    r0 = np.clip(sy, 0, sh - 1)
+    r1 = np.clip(sy + 1, 0, sh - 1)
+    D = (((b0[:, None] * (H[r0] >> 4)) >> 16) + ((b1[:, None] * (H[r1] >> 4)) >> 16) + 2) >> 2
+    return D.astype(np.uint8)
+
+
+def test_resize_constant_and_numpy():
+    const = np.full((100, 240), 137, np.uint8)
+    assert (O.resize(const, 200, 83) == 137).all()
+    img = synth.textured_image(1241, 376, 11)
+    cur = img
+    crcs = []
+    for (dw, dh) in [(1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]:
+        a, b = O.resize(cur, dw, dh), np_resize(cur, dw, dh)
+        assert np.array_equal(a, b)
+        cur = a
+        crcs.append(hashlib.sha256(a.tobytes()).hexdigest()[:8])
+    assert len(set(crcs)) == 7
+
+
+def test_resize_tables_known():
+    ofs, coef = O.resize_tables(1241, 1034)
+    # first output pixel: fx = 0.5*1241/1034 - 0.5 = 0.10009..., a1 = round(0.1000967*2048) = 205
+    assert ofs[0] == 0 and coef[0].tolist() == [1843, 205]
+    assert (coef.sum(1) >= 2047).all() and (coef.sum(1) <= 2049).all()
+    assert ofs.max() <= 1240 and (np.diff(ofs) >= 1).all()
+
+
+def test_resize_horizontal_ramp_monotone():
+    ramp = np.tile(np.arange(240, dtype=np.uint8), (50, 1))
+    out = O.resize(ramp, 200, 42)
+    assert (np.diff(out.astype(int), axis=1) >= 0).all()
+    assert np.abs(out.astype(int) - out[0].astype(int)).max() <= 1   # per-term truncation in the vertical pass
+
+
+# ---------------------------------------------------------------- (5) blur
+def np_gauss7(src):
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    h, w = src.shape
+
+    def refl(p, n):
+        p = np.where(p < 0, -p, p)
+        return np.where(p >= n, 2 * (n - 1) - p, p)
+
+    S = src.astype(np.int64)
+    R = sum(k[i] * S[:, refl(np.arange(w) + i - 3, w)] for i in range(7))
+    D = sum(k[j] * R[refl(np.arange(h) + j - 3, h)] for j in range(7))
+    return np.clip((D + 32768) >> 16, 0, 255).astype(np.uint8)
+
+
+def test_gauss_kernel_ints():
+    assert O.gauss7_kernel().tolist() == [18, 34, 49, 55, 49, 34, 18]
+
+
+def test_gauss_impulse_and_saturation():
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    img = np.zeros((21, 21), np.uint8)
+    img[10, 10] = 255
+    out = O.gauss7(img)
+    exp = ((np.outer(k, k) * 255 + 32768) >> 16).astype(np.uint8)
+    assert np.array_equal(out[7:14, 7:14], exp) and out.sum() == exp.sum()
+    assert (O.gauss7(np.full((30, 40), 255, np.uint8)) == 255).all()   # 257*257*255 > 65535*255 -> saturates
+    assert (O.gauss7(np.full((30, 40), 77, np.uint8)) == ((77 * 257 * 257 + 32768) >> 16)).all()
+
+
+def test_gauss_vs_numpy_with_borders():
+    for seed, (w, h) in enumerate([(346, 105), (64, 20), (9, 7), (533, 400)]):
+        img = synth.textured_image(w, h, 40 + seed)
+        assert np.array_equal(O.gauss7(img), np_gauss7(img))
+
+
+# ---------------------------------------------------------------- (6) Hamming
+def test_hamming_kat():
+    z = np.zeros(32, np.uint8)
+    o = np.full(32, 255, np.uint8)
+    assert O.hamming(z, z) == 0 and O.hamming(z, o) == 256 and O.hamming(o, o) == 0
+    for bit in (0, 7, 8, 100, 255):
+        v = z.copy()
+        v[bit >> 3] |= 1 << (bit & 7)
+        assert O.hamming(z, v) == 1 and O.hamming(o, v) == 255
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (200, 32)).astype(np.uint8)
+    b = rng.integers(0, 256, (200, 32)).astype(np.uint8)
+    ref = np.unpackbits(a ^ b, axis=1).sum(1)
+    assert [O.hamming(a[i], b[i]) for i in range(200)] == ref.tolist()
+
+
+def test_knn2_update_rule():
+    q = np.zeros((1, 32), np.uint8)
+    r = np.zeros((4, 32), np.uint8)
+    r[0, 0] = 0b111      # d=3
+    r[1, 0] = 0b1        # d=1
+    r[2, 0] = 0b10       # d=1 (tie: first minimum wins, second == best)
+    r[3, 0] = 0b11       # d=2
+    bd, bi, sd = O.knn2(q, r)
+    assert (bd[0], bi[0], sd[0]) == (1, 1, 1)
+    bd, bi, sd = O.knn2(q, r[:1])
+    assert (bd[0], bi[0], sd[0]) == (3, 0, 256)
+
+
+# ---------------------------------------------------------------- (7) quadtree
+def test_octree_four_quadrants():
+    pts = np.array([[10, 10, 5], [90, 10, 6], [10, 90, 7], [90, 90, 8]], np.float32)
+    out = O.distribute_octree(pts, 0, 100, 0, 100, 4)
+    # one root (100x100), one split; children pushed to the front in order n1..n4 -> list order n4,n3,n2,n1
+    assert out.tolist() == [[90, 90, 8], [10, 90, 7], [90, 10, 6], [10, 10, 5]]
+
+
+def test_octree_best_response_first_wins():
+    pts = np.array([[10, 10, 5], [12, 12, 9], [14, 14, 9], [90, 90, 1]], np.float32)
+    out = O.distribute_octree(pts, 0, 100, 0, 100, 2)
+    assert out.tolist() == [[90, 90, 1], [12, 12, 9]]
+
+
+def test_octree_count_bounds():
+    img = synth.textured_image(1241, 376, 21)
+    c = O.fast_cells(img)
+    for N in (50, 434, 2000):
+        out = O.distribute_octree(c, 16, 1241 - 16, 16, 376 - 16, N)
+        assert N <= len(out) <= N + 3 or len(out) == len(c)
+        keys = {(x, y) for x, y, _ in out.tolist()}
+        assert len(keys) == len(out) and keys <= {(x, y) for x, y, _ in c.tolist()}
+
+
+# ---------------------------------------------------------------- (8) orientation / descriptor
+def test_ic_angle_gradient_images():
+    um = O.OracleExtractor().tables()["umax"]
+    xs = np.arange(64)
+    right = np.tile((xs * 3).astype(np.uint8), (64, 1))       # brighter to the right -> centroid at +x -> 0 deg
+    down = np.ascontiguousarray(right.T)                      # brighter downwards -> +y -> 90 deg
+    assert O.ic_angle(right, 32, 32, um) == 0.0
+    assert O.ic_angle(down, 32, 32, um) == 90.0
+    assert O.ic_angle(np.ascontiguousarray(right[:, ::-1]), 32, 32, um) == 180.0
+    assert O.ic_angle(np.ascontiguousarray(down[::-1]), 32, 32, um) == 270.0
+
+
+def test_descriptor_angle0_direct_taps():
+    """At angle 0, a=1,b=0: tap (px,py) reads center[py][px]; compare with a direct numpy evaluation."""
+    pat = np.loadtxt((O.ROOT / "oracle" / "pattern31.inc").open(), delimiter=",", comments="//",
+                     usecols=range(16), dtype=np.int64).reshape(256, 4)
+    img = synth.textured_image(80, 80, 77)
+    d = O.descriptor(img, 40, 40, 0.0)
+    bits = [(int(img[40 + y0, 40 + x0]) < int(img[40 + y1, 40 + x1])) for x0, y0, x1, y1 in pat]
+    exp = np.packbits(np.array(bits, np.uint8), bitorder="little")
+    assert np.array_equal(d, exp)
+    # 90 degrees: a = cos(pi/2 as float) ~ -4.4e-8, b = 1 -> row = px, col = -py (rounding absorbs the tiny a)
+    d90 = O.descriptor(img, 40, 40, 90.0)
+    bits = [(int(img[40 + x0, 40 - y0]) < int(img[40 + x1, 40 - y1])) for x0, y0, x1, y1 in pat]
+    assert np.array_equal(d90, np.packbits(np.array(bits, np.uint8), bitorder="little"))
+
+
+def test_pattern_table_pinned():
+    a = (O.ROOT / "oracle" / "pattern31.inc").read_bytes()
+    b = (O.ROOT / "orb_slam2_amd" / "csrc" / "pattern31.inc").read_bytes()
+    assert a == b
+    vals = np.loadtxt((O.ROOT / "oracle" / "pattern31.inc").open(), delimiter=",", comments="//", usecols=range(16),
+                      dtype=np.int64).reshape(-1)
+    assert len(vals) == 1024 and vals.min() >= -13 and vals.max() <= 13
+    assert hashlib.sha256(vals.astype(np.int8).tobytes()).hexdigest() == \
+        "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    assert vals[:8].tolist() == [8, -3, 9, 5, 4, 2, 7, -12]   # first two pairs as printed in the ORB paper's table
+
+
+# ---------------------------------------------------------------- (9) end to end
+def test_extract_end_to_end_invariants(kitti_frame):
+    e = O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    kps, desc = e.extract(kitti_frame)
+    assert 2000 <= len(kps) <= 2000 + 3 * 8
+    assert desc.shape == (len(kps), 32)
+    t = e.tables()
+    assert (np.diff(kps["octave"]) >= 0).all()
+    for l in range(8):
+        m = kps["octave"] == l
+        lw, lh = e.level(l).shape[::-1]
+        x, y = kps["x"][m] / t["scale"][l], kps["y"][m] / t["scale"][l]
+        assert (x > 18.9).all() and (x < lw - 19.9).all() and (y > 18.9).all() and (y < lh - 19.9).all()
+        assert (kps["size"][m] == float(int(31 * t["scale"][l]))).all()
+    assert ((kps["angle"] >= 0) & (kps["angle"] < 360)).all() and (kps["class_id"] == -1).all()
+    # re-running is deterministic
+    k2, d2 = e.extract(kitti_frame)
+    assert np.array_equal(kps, k2) and np.array_equal(desc, d2)
+    # empty image: outputs untouched / zero keypoints
+    k0, d0 = O.OracleExtractor().extract(np.zeros((376, 1241), np.uint8))
+    assert len(k0) == 0
