@@ -1,0 +1,164 @@
+/*
+ * orbfe.h -- C-ABI of the MI355X-native ORB front end (liborbfe.so).
+ *
+ * This is the drop-in boundary for ORB-SLAM2's data-parallel front end.  The
+ * reference has no FFI layer: the boundary is the C++ class interface of
+ * ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-111) and
+ * ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:41-106) compiled into
+ * libORB_SLAM2.so.  include/ORBextractor.h and include/ORBmatcher.h of THIS
+ * repository re-declare those two classes with the reference signatures on
+ * top of the entry points below, so Frame / Tracking / LocalMapping /
+ * LoopClosing link unchanged.
+ *
+ * Conventions: plain pointers and sizes only; every function returns
+ * ORBFE_OK (0) or a negative orbfe_status and never throws;
+ * orbfe_last_error() gives a thread-local message.  "host" pointers are
+ * ordinary memory, "dev" pointers are HIP device memory of the handle's GPU.
+ * All kernels are hand-written HIP for gfx950; there is no CPU fallback: if
+ * no GPU / code object is available every compute entry point fails with
+ * ORBFE_ERR_DEVICE.
+ */
+#ifndef ORBFE_H_
+#define ORBFE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum orbfe_status {
+    ORBFE_OK = 0,
+    ORBFE_ERR_ARG = -1,      /* bad argument (null pointer, size, alignment) */
+    ORBFE_ERR_DEVICE = -2,   /* HIP error / no device / kernel image missing */
+    ORBFE_ERR_CAPACITY = -3, /* caller buffer or internal capacity too small */
+    ORBFE_ERR_UNSUPPORTED = -4
+} orbfe_status;
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:51-52; values per dataset in
+ * Examples/Stereo/KITTI00-02.yaml:38-51 etc.). */
+typedef struct orbfe_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} orbfe_params;
+
+/* Layout-identical to cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id = 28 bytes), the element
+ * type of the `keypoints` output of ORBextractor::operator() (include/ORBextractor.h:59-61). */
+typedef struct orbfe_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbfe_keypoint;
+
+typedef struct orbfe_extractor orbfe_extractor;
+
+const char *orbfe_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int orbfe_device_count(void);
+
+/* ------------------------------------------------------------------ ORBextractor ------------------------- */
+
+/* replaces ORBextractor::ORBextractor (src/ORBextractor.cc:410-470): scale tables, per-level quotas, umax, pattern.
+ * One handle = one extractor object = one HIP stream + workspace on `device`.  Handles are not re-entrant; distinct
+ * handles may be used from distinct threads (src/Frame.cc:78-81 runs two extractors concurrently). */
+int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extractor **out);
+int orbfe_extractor_destroy(orbfe_extractor *e);
+
+/* replaces the getters GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (include/ORBextractor.h:63-83) and exposes mnFeaturesPerLevel / umax (:103-105).  Any pointer may be NULL.
+ * scale..inv_sigma2 and features_per_level hold nlevels entries, umax 16. */
+int orbfe_get_tables(const orbfe_extractor *e, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                     int32_t *features_per_level, int32_t *umax);
+
+/* replaces ORBextractor::operator() (src/ORBextractor.cc:1043-1105) for one host image.
+ * img: 8-bit single channel, h rows of w pixels, `stride` bytes between rows (any stride, cv::Mat::step).
+ * kps[cap], desc32[cap*32]: host outputs, level-major order exactly as the reference; *n_out = keypoint count.
+ * An empty image (img NULL or w,h <= 0) returns ORBFE_OK with *n_out = 0 and outputs untouched (:1046-1047).
+ * cap too small -> ORBFE_ERR_CAPACITY with *n_out = required count. */
+int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stride, orbfe_keypoint *kps, int cap,
+                  uint8_t *desc32, int *n_out);
+
+/* Batched form of the same operator for independent frames that are ALREADY RESIDENT in device memory
+ * (BASELINE.json config "batched offline extraction"; no counterpart call in the reference, which extracts one
+ * frame per call at src/Frame.cc:247-253).  Frame f starts at dev_imgs + f*frame_stride, rows `stride` bytes
+ * apart; dev_imgs, stride and frame_stride must be multiples of 16.
+ * Outputs (device): dev_kps[n_frames][cap], dev_desc[n_frames][cap][32], dev_counts[n_frames].
+ * The call is asynchronous on the handle's stream unless `sync` is non-zero.  If a frame yields more than `cap`
+ * keypoints its count is still reported in full and only the first `cap` entries are written. */
+int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frames, int w, int h, int stride,
+                        size_t frame_stride, orbfe_keypoint *dev_kps, uint8_t *dev_desc, int32_t *dev_counts, int cap,
+                        int sync);
+int orbfe_synchronize(orbfe_extractor *e);
+
+/* replaces the public member std::vector<cv::Mat> mvImagePyramid (include/ORBextractor.h:85; read by
+ * src/Frame.cc:473,563,575,580).  Copies level `level` of frame `frame` of the LAST call into host memory laid out
+ * like the reference's buffer: (w+38) x (h+38) bytes, row pitch w+38, 19-px BORDER_REFLECT_101 frame
+ * (src/ORBextractor.cc:1113-1128); the ROI the reference exposes starts at dst + 19*(w+38) + 19.
+ * dst may be NULL to query the size only. */
+int orbfe_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst, size_t dst_bytes, int *w, int *h);
+
+/* Stage outputs of the last call, for stage-wise parity tests (no counterpart in the reference; its stages are
+ * private members, include/ORBextractor.h:87-95).  what: 0 = pyramid level ROI (u8 w*h), 1 = blurred level (u8 w*h),
+ * 2 = FAST candidates in reference order as float triples (x, y, response), x/y relative to minBorder (16),
+ * 3 = keypoints kept by DistributeOctTree for the level as float quads (x, y, response, angle), level coordinates.
+ * Returns the number of bytes the stage holds in *bytes; copies min(*bytes, dst_bytes). */
+int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *dst, size_t dst_bytes, size_t *bytes);
+
+/* ------------------------------------------------------------------ ORBmatcher --------------------------- */
+
+/* replaces ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663) and its twin DBoW2::FORB::distance
+ * (Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101): Hamming distance of two 32-byte descriptors, host side (the callers pass
+ * single cv::Mat rows; a device launch per pair would be absurd). */
+int orbfe_hamming(const uint8_t *a32, const uint8_t *b32);
+
+typedef struct orbfe_matcher orbfe_matcher;
+/* A matcher context = HIP stream + scratch on `device`.  ORBmatcher objects are stateless temporaries used from three
+ * threads (include/ORBmatcher.h:100-101); contexts are cheap, create one per thread. */
+int orbfe_matcher_create(int device, orbfe_matcher **out);
+int orbfe_matcher_destroy(orbfe_matcher *m);
+
+/* Brute-force best / second-best Hamming search: the inner loops of ORBmatcher::SearchByBoW
+ * (src/ORBmatcher.cc:205-226, 570-596) over a whole reference set, and the 1M-descriptor relocalisation config.
+ * Update rule as in the reference: `if d<best {second=best; best=d; idx=j} else if d<second {second=d}` scanning
+ * j ascending from best=second=256: the first minimum wins, second may equal best.  nr == 0 gives (256, -1, 256).
+ * All pointers are device memory; q[nq][32], r[nr][32]; outputs int32[nq].  idx_base is added to every index
+ * (global numbering of a database shard). */
+int orbfe_match_knn2(orbfe_matcher *m, const uint8_t *dev_q, int nq, const uint8_t *dev_r, int nr, int32_t idx_base,
+                     int32_t *dev_best_dist, int32_t *dev_best_idx, int32_t *dev_second_dist, int sync);
+
+/* Candidate-list form: the inner loops of SearchByProjection / Fuse / SearchBySim3 / SearchForInitialization
+ * (src/ORBmatcher.cc:83-115, 372-392, 436-461, 1400-1424, ...), where the host produces for query i the candidate
+ * rows cand_idx[cand_off[i] .. cand_off[i+1]) of r (GetFeaturesInArea, src/Frame.cc:327-380).  Same update rule,
+ * candidates scanned in list order.  Device pointers; cand_off has nq+1 entries. */
+int orbfe_match_csr(orbfe_matcher *m, const uint8_t *dev_q, int nq, const uint8_t *dev_r, int nr,
+                    const int32_t *dev_cand_off, const int32_t *dev_cand_idx, int32_t *dev_best_dist,
+                    int32_t *dev_best_idx, int32_t *dev_second_dist, int sync);
+
+/* replaces the Hamming row-band search of Frame::ComputeStereoMatches (src/Frame.cc:476-549): for every left keypoint
+ * the right keypoint with the smallest distance among those whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave],
+ * contains (int)vL, whose octave is within +-1 and whose uR lies in [uL-max_d, uL-min_d]; strict '<' from
+ * best = TH_HIGH = 100, lowest right index wins ties.  Outputs best_dist[nl] (100 when nothing beat it) and
+ * best_idx[nl] (0 in that case, as the reference's bestIdxR).  Device pointers; kps are orbfe_keypoint arrays. */
+int orbfe_stereo_rowband(orbfe_matcher *m, const orbfe_keypoint *dev_kl, const uint8_t *dev_dl, int nl,
+                         const orbfe_keypoint *dev_kr, const uint8_t *dev_dr, int nr, const float *host_scale_factors,
+                         int nlevels, int nrows, float min_d, float max_d, int32_t *dev_best_dist, int32_t *dev_best_idx,
+                         int sync);
+int orbfe_matcher_synchronize(orbfe_matcher *m);
+/* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
+void *orbfe_matcher_stream(orbfe_matcher *m);
+void *orbfe_extractor_stream(orbfe_extractor *e);
+
+/* Merge of per-shard kNN-2 results for a database sharded over several GPUs: given S shards'
+ * (best_dist, best_idx, second_dist) for nq queries laid out [S][nq], produce the result the unsharded scan would
+ * give: best = lowest distance then lowest global index; second = second smallest of the multiset of all shards'
+ * best and second.  Host pointers (the gathered buffers are 12 bytes per query and shard). */
+int orbfe_merge_knn2(const int32_t *best_dist, const int32_t *best_idx, const int32_t *second_dist, int n_shards, int nq,
+                     int32_t *out_best_dist, int32_t *out_best_idx, int32_t *out_second_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H_ */

@@ -1,0 +1,260 @@
+"""ctypes binding of liborbfe.so (the C-ABI declared in include/orbfe.h).
+
+This is plumbing for tests and bench.py: the product is the shared library.  There is NO CPU fallback -- if the
+library is missing, or no GPU is visible when a compute entry point is called, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "liborbfe.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+ORBFE_OK, ERR_ARG, ERR_DEVICE, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+
+# every symbol include/orbfe.h declares (tests check that the library exports exactly these)
+EXPORTS = [
+    "orbfe_last_error", "orbfe_device_count", "orbfe_extractor_create", "orbfe_extractor_destroy", "orbfe_get_tables",
+    "orbfe_extract", "orbfe_extract_batch", "orbfe_synchronize", "orbfe_pyramid_level", "orbfe_debug_stage",
+    "orbfe_hamming", "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_match_knn2", "orbfe_match_csr",
+    "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
+    "orbfe_merge_knn2",
+]
+
+
+class OrbfeParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"orbfe error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+vp, u8p, f32p, i32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+
+def lib():
+    """Load liborbfe.so (built in-tree by __graft_entry__.build() / make -C orb_slam2_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_slam2_amd/csrc` "
+                          "(the HIP library is the product; there is no fallback)")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  Loading torch first makes the dynamic
+    # linker bind liborbfe's libamdhip64.so.7 dependency to that copy; the other order leaves two runtimes in the
+    # process and torch then reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(str(LIB_PATH))
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_extractor_create.argtypes = [C.POINTER(OrbfeParams), C.c_int, C.POINTER(vp)]
+    L.orbfe_extractor_destroy.argtypes = [vp]
+    L.orbfe_get_tables.argtypes = [vp, f32p, f32p, f32p, f32p, i32p, i32p]
+    L.orbfe_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, i32p]
+    L.orbfe_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, C.c_int]
+    L.orbfe_synchronize.argtypes = [vp]
+    L.orbfe_pyramid_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, i32p, i32p]
+    L.orbfe_debug_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orbfe_hamming.argtypes = [vp, vp]
+    L.orbfe_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.orbfe_matcher_destroy.argtypes = [vp]
+    L.orbfe_match_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
+    L.orbfe_match_csr.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    L.orbfe_stereo_rowband.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                       vp, vp, C.c_int]
+    L.orbfe_matcher_synchronize.argtypes = [vp]
+    L.orbfe_matcher_stream.restype = vp
+    L.orbfe_matcher_stream.argtypes = [vp]
+    L.orbfe_extractor_stream.restype = vp
+    L.orbfe_extractor_stream.argtypes = [vp]
+    L.orbfe_merge_knn2.argtypes = [i32p, i32p, i32p, C.c_int, C.c_int, i32p, i32p, i32p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise OrbfeError(rc, lib().orbfe_last_error().decode())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(vp)
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-111) over the C-ABI."""
+
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0):
+        self._L = lib()
+        self._h = vp()
+        self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
+        self._scaleFactor = float(np.float32(scaleFactor))
+        p = OrbfeParams(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
+        check(self._L.orbfe_extractor_create(C.byref(p), int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbfe_extractor_destroy(self._h)
+            self._h = vp()
+
+    __del__ = close
+
+    # ---- getters (include/ORBextractor.h:63-83)
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return self._scaleFactor
+
+    def _tables(self):
+        n = self.nlevels
+        s, i, s2, i2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl, um = np.zeros(n, np.int32), np.zeros(16, np.int32)
+        check(self._L.orbfe_get_tables(self._h, s.ctypes.data_as(f32p), i.ctypes.data_as(f32p), s2.ctypes.data_as(f32p),
+                                       i2.ctypes.data_as(f32p), fpl.ctypes.data_as(i32p), um.ctypes.data_as(i32p)))
+        return dict(scale=s, inv_scale=i, sigma2=s2, inv_sigma2=i2, features_per_level=fpl, umax=um)
+
+    def GetScaleFactors(self):
+        return self._tables()["scale"]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()["inv_scale"]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()["sigma2"]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()["inv_sigma2"]
+
+    # ---- operator() (include/ORBextractor.h:59-61); the mask is ignored as in the reference (:58)
+    def __call__(self, image: np.ndarray, mask=None):
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 image expected (reference asserts the same)"
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        rc = self._L.orbfe_extract(self._h, _np_ptr(image), image.shape[1], image.shape[0], image.strides[0], _np_ptr(kps),
+                                   cap, _np_ptr(desc), C.byref(n))
+        if rc == ERR_CAPACITY and n.value > cap:
+            cap = n.value
+            kps = np.zeros(cap, KP_DTYPE)
+            desc = np.zeros((cap, 32), np.uint8)
+            rc = self._L.orbfe_extract(self._h, _np_ptr(image), image.shape[1], image.shape[0], image.strides[0],
+                                       _np_ptr(kps), cap, _np_ptr(desc), C.byref(n))
+        check(rc)
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_device(self, dev_imgs_ptr: int, n_frames, w, h, stride, frame_stride, dev_kps_ptr, dev_desc_ptr,
+                             dev_counts_ptr, cap, sync=True):
+        """Batched extraction on frames resident in HBM; pointers are raw device addresses (e.g. tensor.data_ptr())."""
+        check(self._L.orbfe_extract_batch(self._h, vp(dev_imgs_ptr), n_frames, w, h, stride, frame_stride, vp(dev_kps_ptr),
+                                          vp(dev_desc_ptr), vp(dev_counts_ptr), cap, 1 if sync else 0))
+
+    def synchronize(self):
+        check(self._L.orbfe_synchronize(self._h))
+
+    def stream(self) -> int:
+        return int(self._L.orbfe_extractor_stream(self._h) or 0)
+
+    # ---- mvImagePyramid (include/ORBextractor.h:85)
+    def pyramid_level(self, level, frame=0, with_border=False):
+        w, h = C.c_int32(), C.c_int32()
+        check(self._L.orbfe_pyramid_level(self._h, frame, level, None, 0, C.byref(w), C.byref(h)))
+        buf = np.zeros((h.value + 38, w.value + 38), np.uint8)
+        check(self._L.orbfe_pyramid_level(self._h, frame, level, _np_ptr(buf), buf.size, C.byref(w), C.byref(h)))
+        return buf if with_border else buf[19:-19, 19:-19]
+
+    @property
+    def mvImagePyramid(self):
+        return [self.pyramid_level(l) for l in range(self.nlevels)]
+
+    def debug_stage(self, level, what, frame=0):
+        nbytes = C.c_size_t(0)
+        check(self._L.orbfe_debug_stage(self._h, frame, level, what, None, 0, C.byref(nbytes)))
+        raw = np.zeros(max(nbytes.value, 1), np.uint8)
+        check(self._L.orbfe_debug_stage(self._h, frame, level, what, _np_ptr(raw), nbytes.value, C.byref(nbytes)))
+        raw = raw[:nbytes.value]
+        if what in (0, 1):
+            w, h = C.c_int32(), C.c_int32()
+            check(self._L.orbfe_pyramid_level(self._h, frame, level, None, 0, C.byref(w), C.byref(h)))
+            return raw.reshape(h.value, w.value)
+        return raw.view(np.float32).reshape(-1, 3 if what == 2 else 4)
+
+
+class ORBmatcher:
+    """Mirror of the Hamming part of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:41-106) over the C-ABI.
+
+    Device-pointer methods take raw device addresses (torch ``tensor.data_ptr()``)."""
+
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30   # src/ORBmatcher.cc:37-39
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self._L = lib()
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+        self._h = vp()
+        check(self._L.orbfe_matcher_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbfe_matcher_destroy(self._h)
+            self._h = vp()
+
+    __del__ = close
+
+    @staticmethod
+    def DescriptorDistance(a: np.ndarray, b: np.ndarray) -> int:
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        assert a.size == 32 and b.size == 32
+        return int(lib().orbfe_hamming(_np_ptr(a), _np_ptr(b)))
+
+    def knn2_device(self, q_ptr, nq, r_ptr, nr, bd_ptr, bi_ptr, sd_ptr, idx_base=0, sync=True):
+        check(self._L.orbfe_match_knn2(self._h, vp(q_ptr), nq, vp(r_ptr), nr, idx_base, vp(bd_ptr), vp(bi_ptr), vp(sd_ptr),
+                                       1 if sync else 0))
+
+    def csr_device(self, q_ptr, nq, r_ptr, nr, off_ptr, idx_ptr, bd_ptr, bi_ptr, sd_ptr, sync=True):
+        check(self._L.orbfe_match_csr(self._h, vp(q_ptr), nq, vp(r_ptr), nr, vp(off_ptr), vp(idx_ptr), vp(bd_ptr), vp(bi_ptr),
+                                      vp(sd_ptr), 1 if sync else 0))
+
+    def stereo_rowband_device(self, kl_ptr, dl_ptr, nl, kr_ptr, dr_ptr, nr, scale_factors, nrows, min_d, max_d, bd_ptr, bi_ptr,
+                              sync=True):
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        check(self._L.orbfe_stereo_rowband(self._h, vp(kl_ptr), vp(dl_ptr), nl, vp(kr_ptr), vp(dr_ptr), nr,
+                                           sf.ctypes.data_as(f32p), len(sf), nrows, min_d, max_d, vp(bd_ptr), vp(bi_ptr),
+                                           1 if sync else 0))
+
+    def synchronize(self):
+        check(self._L.orbfe_matcher_synchronize(self._h))
+
+    def stream(self) -> int:
+        return int(self._L.orbfe_matcher_stream(self._h) or 0)
+
+
+def merge_knn2(best_dist, best_idx, second_dist):
+    """Fold per-shard results [S, nq] into the unsharded answer (include/orbfe.h: orbfe_merge_knn2)."""
+    bd = np.ascontiguousarray(best_dist, np.int32)
+    bi = np.ascontiguousarray(best_idx, np.int32)
+    sd = np.ascontiguousarray(second_dist, np.int32)
+    S, nq = bd.shape
+    obd, obi, osd = (np.zeros(nq, np.int32) for _ in range(3))
+    check(lib().orbfe_merge_knn2(bd.ctypes.data_as(i32p), bi.ctypes.data_as(i32p), sd.ctypes.data_as(i32p), S, nq,
+                                 obd.ctypes.data_as(i32p), obi.ctypes.data_as(i32p), osd.ctypes.data_as(i32p)))
+    return obd, obi, osd

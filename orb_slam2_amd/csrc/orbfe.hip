@@ -1,0 +1,668 @@
+// orbfe.hip -- host side of liborbfe.so: the C-ABI of include/orbfe.h on top of the gfx950 kernels in k_*.h.
+//
+// Mirrors ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-111, src/ORBextractor.cc) and the Hamming part
+// of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:41-106, src/ORBmatcher.cc).  Compiled with -ffp-contract=off so the
+// float arithmetic restated from the reference (scale tables, resize coefficients) is evaluated as written.
+#include "../../include/orbfe.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "k_blur.h"
+#include "k_describe.h"
+#include "k_fast.h"
+#include "k_match.h"
+#include "k_pyramid.h"
+#include "quadtree_host.h"
+
+using namespace orbfe;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return fail(ORBFE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                                              std::to_string(__LINE__) + ")");                                \
+    } while (0)
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+inline int cv_round(double v) { return (int)std::nearbyint(v); }   // cvRound: ties to even
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+// =====================================================================================================================
+struct orbfe_extractor {
+    orbfe_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // constructor tables (reference src/ORBextractor.cc:415-469)
+    double scaleFactor = 1.0;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    // geometry for the current input size
+    Geom g;
+    bool haveGeom = false;
+    std::vector<RszTab> hRsz;           // all levels' x and y tables
+    std::vector<int> rszLdsPitch, rszLdsRows;
+    std::vector<BlurTile> hBlurTiles;
+    DevBuf dRsz, dBlurTiles;
+    // per-batch workspace
+    DevBuf dPyr, dBlur, dCand, dLevelCount, dCellTab, dSel, dSelCount;
+    PinBuf hCand, hLevelCount, hCellTab, hSel, hSelCount;
+    // single-image path
+    DevBuf dImg, dKps, dDesc, dCounts;
+    PinBuf hKps, hDesc, hCounts;
+    // last call (for orbfe_pyramid_level / orbfe_debug_stage)
+    ImgSrc last{};
+    int lastFrames = 0;
+    std::vector<std::vector<Cand>> lastOrdered;   // [frame*nlevels + level] candidates in reference order
+    bool overflow = false;
+};
+
+namespace {
+
+// ORBextractor::ORBextractor, reference src/ORBextractor.cc:410-470
+void build_tables(orbfe_extractor *e) {
+    const int nlevels = e->p.nlevels;
+    e->scaleFactor = e->p.scale_factor;   // double member initialised from the float argument (include/ORBextractor.h:98)
+    e->mvScaleFactor.assign(nlevels, 1.0f);
+    e->mvLevelSigma2.assign(nlevels, 1.0f);
+    for (int i = 1; i < nlevels; i++) {
+        e->mvScaleFactor[i] = (float)(e->mvScaleFactor[i - 1] * e->scaleFactor);
+        e->mvLevelSigma2[i] = e->mvScaleFactor[i] * e->mvScaleFactor[i];
+    }
+    e->mvInvScaleFactor.resize(nlevels);
+    e->mvInvLevelSigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+        e->mvInvScaleFactor[i] = 1.0f / e->mvScaleFactor[i];
+        e->mvInvLevelSigma2[i] = 1.0f / e->mvLevelSigma2[i];
+    }
+    e->mnFeaturesPerLevel.resize(nlevels);
+    const float factor = (float)(1.0f / e->scaleFactor);
+    float nDesired = e->p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        e->mnFeaturesPerLevel[level] = cv_round(nDesired);
+        sum += e->mnFeaturesPerLevel[level];
+        nDesired *= factor;
+    }
+    e->mnFeaturesPerLevel[nlevels - 1] = std::max(e->p.nfeatures - sum, 0);
+    // umax (:454-469)
+    e->umax.assign(kHalfPatch + 1, 0);
+    int v, v0;
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+        e->umax[v] = v0;
+        ++v0;
+    }
+}
+
+// cv::resize INTER_LINEAR coefficient set-up (OpenCV 2.4/3.2 generic path)
+void resize_table(int ssize, int dsize, bool isX, int padTo, std::vector<RszTab> &out) {
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    const size_t base = out.size();
+    for (int d = 0; d < dsize; d++) {
+        float fr = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(fr);
+        fr -= s;
+        if (isX) {
+            if (s < 0) { fr = 0; s = 0; }
+            if (s >= ssize - 1) { fr = 0; s = ssize - 1; }
+        }
+        auto sat16 = [](float v) { int i = cv_round(v); return i < -32768 ? -32768 : i > 32767 ? 32767 : i; };
+        const int c0 = sat16((1.f - fr) * 2048), c1 = sat16(fr * 2048);
+        RszTab t;
+        t.ofs = s;
+        t.coef = (c0 & 0xffff) | (c1 << 16);
+        out.push_back(t);
+    }
+    const int padded = round_up(dsize, padTo);
+    for (int d = dsize; d < padded; d++) out.push_back(out[base + dsize - 1]);
+}
+
+int build_geometry(orbfe_extractor *e, int w, int h) {
+    if (e->haveGeom && e->g.w0 == w && e->g.h0 == h) return ORBFE_OK;
+    Geom &g = e->g;
+    memset(&g, 0, sizeof(g));
+    const int nl = e->p.nlevels;
+    g.nlevels = nl;
+    g.w0 = w;
+    g.h0 = h;
+    e->hRsz.clear();
+    e->hBlurTiles.clear();
+    e->rszLdsPitch.assign(nl, 0);
+    e->rszLdsRows.assign(nl, 0);
+    int pyrOff = 0, blurOff = 0, cellBase = 0, candOff = 0, selOff = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelGeom &L = g.lv[l];
+        const float scale = e->mvInvScaleFactor[l];
+        L.w = cv_round((float)w * scale);   // reference src/ORBextractor.cc:1111-1112
+        L.h = cv_round((float)h * scale);
+        L.pitch = round_up(L.w, kPitchAlign);
+        if (L.w > 65535 || L.h > 65535) return fail(ORBFE_ERR_UNSUPPORTED, "image larger than 65535 pixels on a side");
+        L.pyrOff = pyrOff;
+        if (l > 0) pyrOff += round_up(L.pitch * L.h, 256);
+        L.blurOff = blurOff;
+        blurOff += round_up(L.pitch * L.h, 256);
+        // FAST cell grid (:773-787)
+        const int maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+        const float width = (float)(maxBX - kMinBorder), height = (float)(maxBY - kMinBorder);
+        L.nCols = (int)(width / 30.f);
+        L.nRows = (int)(height / 30.f);
+        if (L.nCols < 1 || L.nRows < 1)
+            return fail(ORBFE_ERR_UNSUPPORTED, "pyramid level " + std::to_string(l) + " is smaller than one 30-px FAST cell "
+                                               "plus borders (the reference divides by zero there)");
+        L.wCell = (int)std::ceil(width / L.nCols);
+        L.hCell = (int)std::ceil(height / L.nRows);
+        if (L.wCell + 6 > kFastMaxWin || L.hCell + 6 > kFastMaxWin || L.wCell > 64)
+            return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell larger than the kernel's LDS window");
+        L.cellBase = cellBase;
+        cellBase += L.nCols * L.nRows;
+        const int detArea = std::max(1, (L.w - 2 * kEdge) * (L.h - 2 * kEdge));
+        L.candCap = std::min(60000, std::max(1024, detArea / 12));
+        L.candOff = candOff;
+        candOff += L.candCap;
+        // quadtree roots (:543-545)
+        L.quota = e->mnFeaturesPerLevel[l];
+        L.nIni = (int)std::round(static_cast<float>(maxBX - kMinBorder) / (maxBY - kMinBorder));
+        if (L.nIni < 1) return fail(ORBFE_ERR_UNSUPPORTED, "portrait level: the reference's nIni rounds to 0");
+        L.hX = static_cast<float>(maxBX - kMinBorder) / L.nIni;
+        L.selCap = std::max(L.quota + 3, 4 * L.nIni) + 1;
+        L.selOff = selOff;
+        selOff += L.selCap;
+        L.scale = e->mvScaleFactor[l];
+        L.patch = (float)(int)(31 * e->mvScaleFactor[l]);   // scaledPatchSize (:837)
+        if (l > 0) {
+            const LevelGeom &P = g.lv[l - 1];
+            L.rszOff = (int)e->hRsz.size();
+            resize_table(P.w, L.w, true, kRszTW, e->hRsz);
+            L.rszOffY = (int)e->hRsz.size();
+            resize_table(P.h, L.h, false, kRszTH, e->hRsz);
+            // LDS footprint of the worst tile
+            const RszTab *xt = &e->hRsz[L.rszOff], *yt = &e->hRsz[L.rszOffY];
+            int maxNd = 1, maxNr = 1;
+            for (int x0 = 0; x0 < L.w; x0 += kRszTW) {
+                const int xl = std::min(x0 + kRszTW, L.w) - 1;
+                const int sx0 = xt[x0].ofs & ~3, sx1 = std::min(xt[xl].ofs + 1, P.w - 1);
+                maxNd = std::max(maxNd, ((sx1 - sx0) >> 2) + 1);
+            }
+            for (int y0 = 0; y0 < L.h; y0 += kRszTH) {
+                const int yl = std::min(y0 + kRszTH, L.h) - 1;
+                const int sy0 = std::min(std::max(yt[y0].ofs, 0), P.h - 1), sy1 = std::min(yt[yl].ofs + 1, P.h - 1);
+                maxNr = std::max(maxNr, sy1 - sy0 + 1);
+            }
+            e->rszLdsPitch[l] = maxNd * 4;
+            e->rszLdsRows[l] = maxNr;
+            if ((size_t)maxNd * 4 * maxNr > 60000)
+                return fail(ORBFE_ERR_UNSUPPORTED, "scale factor too large for the resize kernel's LDS tile");
+        }
+        for (int ty = 0; ty * kBlurTH < L.h; ty++)
+            for (int tx = 0; tx * kBlurTW < L.w; tx++) {
+                BlurTile t;
+                t.level = (uint16_t)l; t.tx = (uint16_t)tx; t.ty = (uint16_t)ty; t.pad = 0;
+                e->hBlurTiles.push_back(t);
+            }
+    }
+    g.totalCells = cellBase;
+    g.pyrFrameBytes = std::max(pyrOff, 256);
+    g.blurFrameBytes = blurOff;
+    g.candFrameCap = candOff;
+    g.selFrameCap = selOff;
+    HIPCHK(e->dRsz.ensure(e->hRsz.size() * sizeof(RszTab) + 16));
+    if (!e->hRsz.empty())
+        HIPCHK(hipMemcpyAsync(e->dRsz.p, e->hRsz.data(), e->hRsz.size() * sizeof(RszTab), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e->dBlurTiles.ensure(e->hBlurTiles.size() * sizeof(BlurTile)));
+    HIPCHK(hipMemcpyAsync(e->dBlurTiles.p, e->hBlurTiles.data(), e->hBlurTiles.size() * sizeof(BlurTile),
+                          hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->haveGeom = true;
+    return ORBFE_OK;
+}
+
+int ensure_workspace(orbfe_extractor *e, int F) {
+    const Geom &g = e->g;
+    HIPCHK(e->dPyr.ensure((size_t)F * g.pyrFrameBytes));
+    HIPCHK(e->dBlur.ensure((size_t)F * g.blurFrameBytes));
+    HIPCHK(e->dCand.ensure((size_t)F * g.candFrameCap * sizeof(Cand)));
+    HIPCHK(e->dLevelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
+    HIPCHK(e->dCellTab.ensure((size_t)F * g.totalCells * sizeof(int2)));
+    HIPCHK(e->dSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
+    HIPCHK(e->dSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
+    HIPCHK(e->hCand.ensure((size_t)F * g.candFrameCap * sizeof(Cand)));
+    HIPCHK(e->hLevelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
+    HIPCHK(e->hCellTab.ensure((size_t)F * g.totalCells * sizeof(int2)));
+    HIPCHK(e->hSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
+    HIPCHK(e->hSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
+    return ORBFE_OK;
+}
+
+// candidates of (frame f, level l) in the reference's order: cells row-major, inside a cell row-major (:789-829)
+void ordered_candidates(const orbfe_extractor *e, int f, int l, std::vector<Cand> &out) {
+    const Geom &g = e->g;
+    const LevelGeom &L = g.lv[l];
+    const int2 *tab = (const int2 *)e->hCellTab.p + (size_t)f * g.totalCells + L.cellBase;
+    const Cand *cand = (const Cand *)e->hCand.p + (size_t)f * g.candFrameCap + L.candOff;
+    out.clear();
+    for (int c = 0; c < L.nCols * L.nRows; c++) {
+        const int off = tab[c].x, n = tab[c].y;
+        for (int k = 0; k < n && off + k < L.candCap; k++) out.push_back(cand[off + k]);
+    }
+}
+
+// The pipeline for F frames resident on the device.  Outputs on the device.
+int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int stride, size_t frameStride,
+              orbfe_keypoint *dKps, uint8_t *dDesc, int32_t *dCounts, int cap) {
+    int rc = build_geometry(e, w, h);
+    if (rc) return rc;
+    rc = ensure_workspace(e, F);
+    if (rc) return rc;
+    const Geom &g = e->g;
+    hipStream_t st = e->stream;
+    ImgSrc src;
+    src.img0 = dImgs;
+    src.pitch0 = stride;
+    src.frameStride0 = frameStride;
+    src.pyr = (uint8_t *)e->dPyr.p;
+    src.blur = (uint8_t *)e->dBlur.p;
+    e->last = src;
+    e->lastFrames = F;
+
+    // K1: pyramid, level by level (level l reads level l-1)
+    for (int l = 1; l < g.nlevels; l++) {
+        const LevelGeom &L = g.lv[l], &P = g.lv[l - 1];
+        ResizeArgs a;
+        int sp;
+        a.src = level_ptr(src, g, 0, l - 1, &sp);
+        a.sPitch = sp;
+        a.sFrameStride = (l - 1 == 0) ? frameStride : (size_t)g.pyrFrameBytes;
+        a.sw = P.w; a.sh = P.h;
+        a.dst = src.pyr + L.pyrOff;
+        a.dPitch = L.pitch;
+        a.dFrameStride = g.pyrFrameBytes;
+        a.dw = L.w; a.dh = L.h;
+        a.xtab = (const RszTab *)e->dRsz.p + L.rszOff;
+        a.ytab = (const RszTab *)e->dRsz.p + L.rszOffY;
+        a.ldsPitch = e->rszLdsPitch[l];
+        a.ldsRows = e->rszLdsRows[l];
+        dim3 grid((L.w + kRszTW - 1) / kRszTW, (L.h + kRszTH - 1) / kRszTH, F);
+        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), (size_t)a.ldsPitch * a.ldsRows, st, a);
+    }
+    // K3: FAST over every cell of every level
+    HIPCHK(hipMemsetAsync(e->dLevelCount.p, 0, (size_t)F * kMaxLevels * sizeof(int), st));
+    {
+        FastArgs a;
+        a.g = g; a.s = src;
+        a.cand = (Cand *)e->dCand.p;
+        a.levelCount = (int *)e->dLevelCount.p;
+        a.cellTab = (int2 *)e->dCellTab.p;
+        a.iniTh = std::min(std::max(e->p.ini_th_fast, 0), 255);
+        a.minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
+        hipLaunchKernelGGL(fast_cells_kernel, dim3(g.totalCells, F), dim3(256), 0, st, a);
+    }
+    // K5: blur of every level
+    hipLaunchKernelGGL(gauss7_kernel, dim3((unsigned)e->hBlurTiles.size(), F), dim3(256), 0, st, g, src,
+                       (const BlurTile *)e->dBlurTiles.p);
+    HIPCHK(hipGetLastError());
+
+    // candidates to the host, DistributeOctTree, kept keypoints back
+    HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->hCellTab.p, e->dCellTab.p, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->hCand.p, e->dCand.p, (size_t)F * g.candFrameCap * sizeof(Cand), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e->overflow = false;
+    {
+        const int *lc = (const int *)e->hLevelCount.p;
+        for (int f = 0; f < F; f++)
+            for (int l = 0; l < g.nlevels; l++)
+                if (lc[f * kMaxLevels + l] > g.lv[l].candCap) e->overflow = true;
+    }
+    e->lastOrdered.assign((size_t)F * g.nlevels, std::vector<Cand>());
+    {
+        const int tasks = F * g.nlevels;
+        int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        nthreads = std::min(nthreads, tasks);
+        std::atomic<int> next(0);
+        auto worker = [&]() {
+            QuadtreeHost qt;
+            std::vector<Cand> kept;
+            for (;;) {
+                const int t = next.fetch_add(1);
+                if (t >= tasks) break;
+                const int f = t / g.nlevels, l = t % g.nlevels;
+                const LevelGeom &L = g.lv[l];
+                std::vector<Cand> &ordered = e->lastOrdered[t];
+                ordered_candidates(e, f, l, ordered);
+                const int width = (L.w - kEdge + 3) - kMinBorder, height = (L.h - kEdge + 3) - kMinBorder;
+                qt.run(ordered.data(), (int)ordered.size(), width, height, L.quota, L.nIni, L.hX, kept);
+                SelKp *sel = (SelKp *)e->hSel.p + (size_t)f * g.selFrameCap + L.selOff;
+                const int n = std::min((int)kept.size(), L.selCap);
+                for (int k = 0; k < n; k++) {
+                    sel[k].x = (uint16_t)(kept[k].x + kMinBorder);   // :843-844
+                    sel[k].y = (uint16_t)(kept[k].y + kMinBorder);
+                    sel[k].resp = kept[k].resp;
+                    sel[k].level = (uint16_t)l;
+                }
+                ((int *)e->hSelCount.p)[f * kMaxLevels + l] = n;
+            }
+        };
+        if (nthreads <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
+            for (auto &th : pool) th.join();
+        }
+    }
+    HIPCHK(hipMemcpyAsync(e->dSel.p, e->hSel.p, (size_t)F * g.selFrameCap * sizeof(SelKp), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->dSelCount.p, e->hSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyHostToDevice, st));
+    // K4 + K6
+    {
+        DescribeArgs a;
+        a.g = g; a.s = src;
+        a.sel = (const SelKp *)e->dSel.p;
+        a.selCount = (const int *)e->dSelCount.p;
+        a.kps = (KeyPointOut *)dKps;
+        a.desc = dDesc;
+        a.counts = dCounts;
+        a.cap = cap;
+        const int maxKp = std::min(g.selFrameCap, cap);
+        hipLaunchKernelGGL(orient_describe_kernel, dim3((maxKp + 3) / 4, F), dim3(256), 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return ORBFE_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char *orbfe_last_error(void) { return g_err.c_str(); }
+
+int orbfe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extractor **out) {
+    if (!params || !out) return fail(ORBFE_ERR_ARG, "null argument");
+    if (params->nlevels < 1 || params->nlevels > kMaxLevels) return fail(ORBFE_ERR_ARG, "nlevels must be in [1,16]");
+    if (!(params->scale_factor > 1.0f) || params->scale_factor > 2.0f)
+        return fail(ORBFE_ERR_UNSUPPORTED, "scale_factor must be in (1, 2]");
+    if (params->nfeatures < 1) return fail(ORBFE_ERR_ARG, "nfeatures must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(ORBFE_ERR_DEVICE, "no HIP device: liborbfe has no CPU path");
+    if (device < 0 || device >= ndev) return fail(ORBFE_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    orbfe_extractor *e = new orbfe_extractor;
+    e->p = *params;
+    e->device = device;
+    build_tables(e);
+    static const int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    if (!std::equal(e->umax.begin(), e->umax.end(), kUmax)) {
+        delete e;
+        return fail(ORBFE_ERR_DEVICE, "umax table mismatch");
+    }
+    hipError_t er = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (er != hipSuccess) {
+        delete e;
+        return fail(ORBFE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(er));
+    }
+    *out = e;
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_destroy(orbfe_extractor *e) {
+    if (!e) return ORBFE_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamDestroy(e->stream);
+    }
+    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
+                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
+        b->release();
+    for (PinBuf *b : {&e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts})
+        b->release();
+    delete e;
+    return ORBFE_OK;
+}
+
+int orbfe_get_tables(const orbfe_extractor *e, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                     int32_t *features_per_level, int32_t *umax) {
+    if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
+    for (int i = 0; i < e->p.nlevels; i++) {
+        if (scale) scale[i] = e->mvScaleFactor[i];
+        if (inv_scale) inv_scale[i] = e->mvInvScaleFactor[i];
+        if (sigma2) sigma2[i] = e->mvLevelSigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = e->mvInvLevelSigma2[i];
+        if (features_per_level) features_per_level[i] = e->mnFeaturesPerLevel[i];
+    }
+    if (umax)
+        for (int i = 0; i < 16; i++) umax[i] = e->umax[i];
+    return ORBFE_OK;
+}
+
+void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream : nullptr; }
+
+int orbfe_synchronize(orbfe_extractor *e) {
+    if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ORBFE_OK;
+}
+
+int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frames, int w, int h, int stride,
+                        size_t frame_stride, orbfe_keypoint *dev_kps, uint8_t *dev_desc, int32_t *dev_counts, int cap,
+                        int sync) {
+    if (!e || !dev_imgs || !dev_kps || !dev_desc || !dev_counts) return fail(ORBFE_ERR_ARG, "null argument");
+    if (n_frames < 1 || w < 1 || h < 1 || cap < 1) return fail(ORBFE_ERR_ARG, "bad size");
+    if (stride < w || (stride & 15) || (frame_stride & 15) || ((uintptr_t)dev_imgs & 15) ||
+        frame_stride < (size_t)stride * h)
+        return fail(ORBFE_ERR_ARG, "dev_imgs, stride and frame_stride must be multiples of 16 (stride >= w)");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap);
+    if (rc) return rc;
+    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
+    return ORBFE_OK;
+}
+
+int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stride, orbfe_keypoint *kps, int cap,
+                  uint8_t *desc32, int *n_out) {
+    if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
+    if (n_out) *n_out = 0;
+    if (!img || w <= 0 || h <= 0) return ORBFE_OK;   // _image.empty(): return with outputs untouched (:1046-1047)
+    if (stride < w) return fail(ORBFE_ERR_ARG, "stride < w");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = build_geometry(e, w, h);
+    if (rc) return rc;
+    const int pitch = round_up(w, kPitchAlign);
+    const size_t fs = (size_t)pitch * h;
+    const int icap = e->g.selFrameCap;
+    HIPCHK(e->dImg.ensure(fs + 256));
+    HIPCHK(e->dKps.ensure((size_t)icap * sizeof(KeyPointOut)));
+    HIPCHK(e->dDesc.ensure((size_t)icap * 32));
+    HIPCHK(e->dCounts.ensure(sizeof(int) * 4));
+    HIPCHK(e->hKps.ensure((size_t)icap * sizeof(KeyPointOut)));
+    HIPCHK(e->hDesc.ensure((size_t)icap * 32));
+    HIPCHK(e->hCounts.ensure(sizeof(int) * 4));
+    HIPCHK(hipMemcpy2DAsync(e->dImg.p, pitch, img, stride, w, h, hipMemcpyHostToDevice, e->stream));
+    rc = run_batch(e, (const uint8_t *)e->dImg.p, 1, w, h, pitch, round_up((int)fs, 16), (orbfe_keypoint *)e->dKps.p,
+                   (uint8_t *)e->dDesc.p, (int32_t *)e->dCounts.p, icap);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->hCounts.p, e->dCounts.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int n = *(int *)e->hCounts.p;
+    if (n_out) *n_out = n;
+    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
+    if (n > cap) return fail(ORBFE_ERR_CAPACITY, "keypoint buffer too small");
+    if (n == 0) return ORBFE_OK;
+    if (!kps || !desc32) return fail(ORBFE_ERR_ARG, "null output");
+    HIPCHK(hipMemcpyAsync(kps, e->dKps.p, (size_t)n * sizeof(KeyPointOut), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(desc32, e->dDesc.p, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ORBFE_OK;
+}
+
+int orbfe_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst, size_t dst_bytes, int *w, int *h) {
+    if (!e || !e->haveGeom || e->lastFrames == 0) return fail(ORBFE_ERR_ARG, "no extraction has run on this handle");
+    if (frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->g.nlevels) return fail(ORBFE_ERR_ARG, "bad index");
+    const LevelGeom &L = e->g.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!dst) return ORBFE_OK;
+    const int bw = L.w + 2 * kEdge, bh = L.h + 2 * kEdge;
+    if (dst_bytes < (size_t)bw * bh) return fail(ORBFE_ERR_CAPACITY, "destination too small");
+    HIPCHK(hipSetDevice(e->device));
+    int pitch;
+    const uint8_t *src = level_ptr(e->last, e->g, frame, level, &pitch);
+    uint8_t *roi = dst + (size_t)kEdge * bw + kEdge;
+    HIPCHK(hipMemcpy2DAsync(roi, bw, src, pitch, L.w, L.h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // copyMakeBorder(..., BORDER_REFLECT_101) (:1122-1128): the frame is API surface only, built on the host
+    auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
+    for (int y = 0; y < L.h; y++) {
+        uint8_t *row = roi + (size_t)y * bw;
+        for (int k = 1; k <= kEdge; k++) {
+            row[-k] = row[refl(-k, L.w)];
+            row[L.w - 1 + k] = row[refl(L.w - 1 + k, L.w)];
+        }
+    }
+    for (int k = 1; k <= kEdge; k++) {
+        memcpy(dst + (size_t)(kEdge - k) * bw, dst + (size_t)(kEdge + refl(-k, L.h)) * bw, bw);
+        memcpy(dst + (size_t)(kEdge + L.h - 1 + k) * bw, dst + (size_t)(kEdge + refl(L.h - 1 + k, L.h)) * bw, bw);
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *dst, size_t dst_bytes, size_t *bytes) {
+    if (!e || !e->haveGeom || e->lastFrames == 0) return fail(ORBFE_ERR_ARG, "no extraction has run on this handle");
+    if (frame < 0 || frame >= e->lastFrames || level < 0 || level >= e->g.nlevels) return fail(ORBFE_ERR_ARG, "bad index");
+    const Geom &g = e->g;
+    const LevelGeom &L = g.lv[level];
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (what == 0 || what == 1) {
+        const size_t need = (size_t)L.w * L.h;
+        if (bytes) *bytes = need;
+        if (!dst || dst_bytes < need) return ORBFE_OK;
+        int pitch;
+        const uint8_t *src;
+        if (what == 0) {
+            src = level_ptr(e->last, g, frame, level, &pitch);
+        } else {
+            src = e->last.blur + (size_t)frame * g.blurFrameBytes + L.blurOff;
+            pitch = L.pitch;
+        }
+        HIPCHK(hipMemcpy2D(dst, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    if (what == 2) {
+        const std::vector<Cand> &c = e->lastOrdered[(size_t)frame * g.nlevels + level];
+        const size_t need = c.size() * 3 * sizeof(float);
+        if (bytes) *bytes = need;
+        if (!dst || dst_bytes < need) return ORBFE_OK;
+        float *o = (float *)dst;
+        for (size_t i = 0; i < c.size(); i++) {
+            o[3 * i] = (float)c[i].x; o[3 * i + 1] = (float)c[i].y; o[3 * i + 2] = (float)c[i].resp;
+        }
+        return ORBFE_OK;
+    }
+    if (what == 3) {
+        const int n = ((const int *)e->hSelCount.p)[frame * kMaxLevels + level];
+        const size_t need = (size_t)n * 4 * sizeof(float);
+        if (bytes) *bytes = need;
+        if (!dst || dst_bytes < need) return ORBFE_OK;
+        const SelKp *sel = (const SelKp *)e->hSel.p + (size_t)frame * g.selFrameCap + L.selOff;
+        float *o = (float *)dst;
+        for (int i = 0; i < n; i++) {
+            o[4 * i] = (float)sel[i].x; o[4 * i + 1] = (float)sel[i].y; o[4 * i + 2] = (float)sel[i].resp; o[4 * i + 3] = -1.f;
+        }
+        return ORBFE_OK;
+    }
+    return fail(ORBFE_ERR_ARG, "unknown stage");
+}
+
+// ------------------------------------------------------------------------------------------------ matcher ----------
+int orbfe_hamming(const uint8_t *a32, const uint8_t *b32) {
+    // ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663): popcount of the XOR of 8 dwords
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a32 + 8 * i, 8);
+        memcpy(&y, b32 + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+}  // extern "C"
+
+#include "matcher_host.inc"
