@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native ORB front end.
+
+Metric (BASELINE.json): ORB extract frames/sec @1241x376, 2000 keypoints, 8 levels; plus Hamming matches/sec.
+
+A "step" is one pass of ORBextractor::operator() over one batch of synthetic KITTI-sized frames that are already resident
+in HBM (orbfe_extract_batch through the C-ABI), keypoints and descriptors left in HBM.  Every rank processes its own
+batch (independent frames: no data-path collective, weak scaling); `value` = frames of all ranks / max-over-ranks time.
+
+Extra objects in the JSON line:
+  roofline     -- the dominant kernel (FAST): algorithmic bytes per launch / its average duration, measured live with HIP
+                  events recorded on the library's own stream around that kernel inside the timed region.
+  cpu_baseline -- the CPU oracle (a port of the reference's path: the reference itself needs OpenCV and cannot be built
+                  here) timed on the host cores of this box on a bounded sample of the same frames (rank 0, N=1 only).
+  hamming      -- brute-force kNN-2 of 2000 queries against a 1M-descriptor database sharded over the ranks
+                  (BASELINE.json config 5), per-shard results gathered with RCCL and merged.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 the driver uses torch.distributed.run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+W, H, NFEATURES, NLEVELS, SCALE, INI_TH, MIN_TH = 1241, 376, 2000, 8, 1.2, 20, 7
+LEVEL_PIXELS = 1444097                      # sum of the 8 level areas at 1241x376
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+N_UNIQUE = 16                               # distinct synthetic frames, tiled to the batch size
+
+
+def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
+    """Time the CPU oracle (tests/oracle_lib.py -> oracle/liborb_oracle.so) on the box's host cores."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as O
+
+    threads = min(16, len(os.sched_getaffinity(0)))     # a 1-GPU box owns a 16-CPU share
+    t, _ = O.time_extract(frames, NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, threads, reps=1)
+    per_pass = max(t, 1e-3)
+    reps = int(max(1, min(200, budget_s / per_pass)))
+    t, kps = O.time_extract(frames, NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, threads, reps=reps)
+    n = len(frames) * reps
+    return {"value": round(n / t, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} extractions ({len(frames)} distinct 1241x376 frames x {reps}) in {t:.1f} s, one frame per thread, "
+                      f"oracle built -O3 -march=x86-64-v3 -ffp-contract=off; {kps / n:.0f} keypoints/frame"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step and rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hamming", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from orb_slam2_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic frames, resident in HBM before anything is timed
+    B = args.batch
+    stride = (W + 63) // 64 * 64
+    uniq = synth.frame_sequence(N_UNIQUE, W, H, first=rank * N_UNIQUE)
+    host = np.zeros((B, H, stride), np.uint8)
+    for i in range(B):
+        host[i, :, :W] = uniq[i % N_UNIQUE]
+    frames = torch.from_numpy(host).to(dev)
+    cap = NFEATURES + 4 * NLEVELS + 32
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex = capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+
+    def step():
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, stride, stride * H, kps.data_ptr(), desc.data_ptr(),
+                                cnt.data_ptr(), cap, sync=True)
+
+    for _ in range(args.warmup):
+        step()
+    ex.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ex.profile()
+    ex.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_frames = B * args.steps * world
+    fps = total_frames / dt
+    kp_per_frame = float(cnt.float().mean().item())
+
+    # ---- roofline of the dominant kernel (FAST): algorithmic bytes = level pixels read + 8 B per candidate written
+    fast_ms = prof["stage_ms"]["fast"] / max(prof["stage_launches"]["fast"], 1)
+    cand_per_frame = prof["candidates"] / max(prof["frames"], 1)
+    fast_bytes = B * (LEVEL_PIXELS + 8 * cand_per_frame)
+    achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
+    stages = {k: round(v / max(args.steps, 1), 4) for k, v in prof["stage_ms"].items()}
+    roofline = {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "ms_per_launch": round(fast_ms, 4), "algorithmic_bytes_per_launch": int(fast_bytes),
+                "stage_ms_per_step": stages}
+
+    # ---- Hamming kNN-2: 2000 queries vs a 1M database sharded over the ranks, RCCL gather of per-shard results
+    hamming = None
+    if not args.no_hamming:
+        NQ, NDB = 2000, 1_000_000
+        shard = NDB // world
+        db = torch.from_numpy(synth.random_descriptors(shard, 7000 + rank)).to(dev)
+        q_host = synth.random_descriptors(NQ, 42)
+        q = torch.from_numpy(q_host).to(dev)
+        res = torch.zeros((3, NQ), dtype=torch.int32, device=dev)
+        m = capi.ORBmatcher(device=local_rank)
+        gathered = torch.zeros((world, 3, NQ), dtype=torch.int32, device=dev) if world > 1 else None
+
+        def hstep():
+            if world > 1:
+                dist.broadcast(q, src=0)
+            m.knn2_device(q.data_ptr(), NQ, db.data_ptr(), shard, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
+                          idx_base=rank * shard, sync=True)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, res)
+                g = gathered.cpu().numpy()
+                return capi.merge_knn2(g[:, 0], g[:, 1], g[:, 2])
+            return None
+
+        for _ in range(3):
+            hstep()
+        barrier()
+        h0 = time.perf_counter()
+        hsteps = 10
+        for _ in range(hsteps):
+            hstep()
+        barrier()
+        hdt = time.perf_counter() - h0
+        if world > 1:
+            tt = torch.tensor([hdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            hdt = float(tt.item())
+        pairs = NQ * shard * world * hsteps
+        lane_ops = pairs * 19 / hdt                   # 8 xor + 8 bcnt + 3 selection ops per pair
+        hamming = {"metric": "hamming_pair_distances_per_sec", "value": round(pairs / hdt, 1), "ms_per_query_batch": round(hdt / hsteps * 1e3, 3),
+                   "queries": NQ, "database": shard * world, "shards": world,
+                   "valu": {"achieved_Tlaneops": round(lane_ops / 1e12, 2), "peak_Tlaneops": 78.6 * world,
+                            "frac": round(lane_ops / 1e12 / (78.6 * world), 4)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(uniq)
+
+    if rank == 0:
+        out = {
+            "metric": "orb_extract_frames_per_sec_1241x376_2000kp_8lvl", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "batched ORB extraction, 1241x376 KITTI-size frames resident in HBM, 2000 features, "
+                                   "8 levels, scale 1.2, FAST 20/7 (BASELINE.json configs[0] shape, configs[3] batching)",
+                       "frames_per_step_per_gpu": B, "keypoints_per_frame": round(kp_per_frame, 1),
+                       "parallelism": f"frames sharded over {world} gpu(s), no collective"},
+            "roofline": roofline, "cpu_baseline": cpu, "hamming": hamming,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

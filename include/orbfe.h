@@ -107,6 +107,22 @@ int orbfe_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst, 
  * Returns the number of bytes the stage holds in *bytes; copies min(*bytes, dst_bytes). */
 int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *dst, size_t dst_bytes, size_t *bytes);
 
+/* Per-stage device timing of the extractor, taken with HIP events recorded on the handle's stream around each
+ * stage's kernel launches inside orbfe_extract / orbfe_extract_batch (no counterpart in the reference, whose only
+ * timing is the wall clock around TrackStereo in Examples/Stereo/stereo_kitti.cc:80-97).  Enabling resets the sums;
+ * while enabled every call ends with an event synchronisation. */
+enum { ORBFE_STAGE_PYRAMID = 0, ORBFE_STAGE_FAST = 1, ORBFE_STAGE_BLUR = 2, ORBFE_STAGE_DESCRIBE = 3,
+       ORBFE_STAGE_QUADTREE = 4, ORBFE_STAGE_COUNT = 5 };
+typedef struct orbfe_profile {
+    double stage_ms[ORBFE_STAGE_COUNT];       /* summed event time per stage */
+    int64_t stage_launches[ORBFE_STAGE_COUNT]; /* kernel launches behind that sum */
+    int64_t frames;                            /* frames processed while profiling */
+    int64_t candidates;                        /* FAST candidates emitted */
+    int64_t keypoints;                         /* keypoints kept */
+} orbfe_profile;
+int orbfe_set_profiling(orbfe_extractor *e, int enable);
+int orbfe_get_profile(const orbfe_extractor *e, orbfe_profile *out);
+
 /* ------------------------------------------------------------------ ORBmatcher --------------------------- */
 
 /* replaces ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663) and its twin DBoW2::FORB::distance

@@ -25,13 +25,20 @@ EXPORTS = [
     "orbfe_extract", "orbfe_extract_batch", "orbfe_synchronize", "orbfe_pyramid_level", "orbfe_debug_stage",
     "orbfe_hamming", "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_match_knn2", "orbfe_match_csr",
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
-    "orbfe_merge_knn2",
+    "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile",
 ]
+
+STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
 
 
 class OrbfeParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class OrbfeProfile(C.Structure):
+    _fields_ = [("stage_ms", C.c_double * 5), ("stage_launches", C.c_int64 * 5), ("frames", C.c_int64),
+                ("candidates", C.c_int64), ("keypoints", C.c_int64)]
 
 
 class OrbfeError(RuntimeError):
@@ -82,6 +89,8 @@ def lib():
     L.orbfe_extractor_stream.restype = vp
     L.orbfe_extractor_stream.argtypes = [vp]
     L.orbfe_merge_knn2.argtypes = [i32p, i32p, i32p, C.c_int, C.c_int, i32p, i32p, i32p]
+    L.orbfe_set_profiling.argtypes = [vp, C.c_int]
+    L.orbfe_get_profile.argtypes = [vp, C.POINTER(OrbfeProfile)]
     _lib = L
     return L
 
@@ -170,6 +179,16 @@ class ORBextractor:
 
     def synchronize(self):
         check(self._L.orbfe_synchronize(self._h))
+
+    def set_profiling(self, enable: bool):
+        check(self._L.orbfe_set_profiling(self._h, 1 if enable else 0))
+
+    def profile(self) -> dict:
+        p = OrbfeProfile()
+        check(self._L.orbfe_get_profile(self._h, C.byref(p)))
+        return dict(stage_ms={n: p.stage_ms[i] for i, n in enumerate(STAGES)},
+                    stage_launches={n: p.stage_launches[i] for i, n in enumerate(STAGES)},
+                    frames=p.frames, candidates=p.candidates, keypoints=p.keypoints)
 
     def stream(self) -> int:
         return int(self._L.orbfe_extractor_stream(self._h) or 0)

@@ -116,6 +116,13 @@ struct orbfe_extractor {
     int lastFrames = 0;
     std::vector<std::vector<Cand>> lastOrdered;   // [frame*nlevels + level] candidates in reference order
     bool overflow = false;
+    // optional per-stage timing with HIP events on the handle's stream (orbfe_set_profiling)
+    bool profiling = false;
+    hipEvent_t ev[8] = {};
+    double stageMs[ORBFE_STAGE_COUNT] = {};
+    long stageLaunches[ORBFE_STAGE_COUNT] = {};
+    long stageFrames = 0;
+    long candTotal = 0, kpTotal = 0;
 };
 
 namespace {
@@ -331,6 +338,8 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     e->last = src;
     e->lastFrames = F;
 
+    const bool prof = e->profiling;
+    if (prof) HIPCHK(hipEventRecord(e->ev[0], st));
     // K1: pyramid, level by level (level l reads level l-1)
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom &L = g.lv[l], &P = g.lv[l - 1];
@@ -353,6 +362,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     }
     // K3: FAST over every cell of every level
     HIPCHK(hipMemsetAsync(e->dLevelCount.p, 0, (size_t)F * kMaxLevels * sizeof(int), st));
+    if (prof) HIPCHK(hipEventRecord(e->ev[1], st));
     {
         FastArgs a;
         a.g = g; a.s = src;
@@ -363,9 +373,11 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
         hipLaunchKernelGGL(fast_cells_kernel, dim3(g.totalCells, F), dim3(256), 0, st, a);
     }
+    if (prof) HIPCHK(hipEventRecord(e->ev[2], st));
     // K5: blur of every level
     hipLaunchKernelGGL(gauss7_kernel, dim3((unsigned)e->hBlurTiles.size(), F), dim3(256), 0, st, g, src,
                        (const BlurTile *)e->dBlurTiles.p);
+    if (prof) HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipGetLastError());
 
     // candidates to the host, DistributeOctTree, kept keypoints back
@@ -420,6 +432,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     HIPCHK(hipMemcpyAsync(e->dSel.p, e->hSel.p, (size_t)F * g.selFrameCap * sizeof(SelKp), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e->dSelCount.p, e->hSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyHostToDevice, st));
     // K4 + K6
+    if (prof) HIPCHK(hipEventRecord(e->ev[4], st));
     {
         DescribeArgs a;
         a.g = g; a.s = src;
@@ -433,6 +446,23 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         hipLaunchKernelGGL(orient_describe_kernel, dim3((maxKp + 3) / 4, F), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
+    if (prof) {
+        HIPCHK(hipEventRecord(e->ev[5], st));
+        HIPCHK(hipEventSynchronize(e->ev[5]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1])); e->stageMs[ORBFE_STAGE_PYRAMID] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); e->stageMs[ORBFE_STAGE_FAST] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); e->stageMs[ORBFE_STAGE_BLUR] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[4], e->ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
+        e->stageLaunches[ORBFE_STAGE_PYRAMID] += g.nlevels - 1;
+        e->stageLaunches[ORBFE_STAGE_FAST] += 1;
+        e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
+        e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
+        e->stageFrames += F;
+        const int *lc = (const int *)e->hLevelCount.p, *sc = (const int *)e->hSelCount.p;
+        for (int f = 0; f < F; f++)
+            for (int l = 0; l < g.nlevels; l++) { e->candTotal += lc[f * kMaxLevels + l]; e->kpTotal += sc[f * kMaxLevels + l]; }
+    }
     return ORBFE_OK;
 }
 
@@ -474,7 +504,30 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         delete e;
         return fail(ORBFE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(er));
     }
+    for (auto &ev : e->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            delete e;
+            return fail(ORBFE_ERR_DEVICE, "hipEventCreate failed");
+        }
     *out = e;
+    return ORBFE_OK;
+}
+
+int orbfe_set_profiling(orbfe_extractor *e, int enable) {
+    if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
+    e->profiling = enable != 0;
+    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; }
+    e->stageFrames = 0;
+    e->candTotal = e->kpTotal = 0;
+    return ORBFE_OK;
+}
+
+int orbfe_get_profile(const orbfe_extractor *e, orbfe_profile *out) {
+    if (!e || !out) return fail(ORBFE_ERR_ARG, "null argument");
+    for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { out->stage_ms[i] = e->stageMs[i]; out->stage_launches[i] = e->stageLaunches[i]; }
+    out->frames = e->stageFrames;
+    out->candidates = e->candTotal;
+    out->keypoints = e->kpTotal;
     return ORBFE_OK;
 }
 
@@ -485,6 +538,8 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamDestroy(e->stream);
     }
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
         b->release();

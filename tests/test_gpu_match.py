@@ -1,0 +1,120 @@
+"""GPU parity of the Hamming matching entry points against the oracle (bit-exact: distances and indices are integers)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from orb_slam2_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _knn2(m, q, r, idx_base=0):
+    nq = len(q)
+    dq, dr = _dev(q), _dev(r if len(r) else np.zeros((1, 32), np.uint8))
+    bd, bi, sd = (torch.zeros(max(nq, 1), dtype=torch.int32, device="cuda") for _ in range(3))
+    m.knn2_device(dq.data_ptr(), nq, dr.data_ptr(), len(r), bd.data_ptr(), bi.data_ptr(), sd.data_ptr(), idx_base)
+    return bd.cpu().numpy()[:nq], bi.cpu().numpy()[:nq], sd.cpu().numpy()[:nq]
+
+
+@pytest.mark.parametrize("nq,nr", [(1, 1), (7, 3), (300, 1000), (2000, 20000), (257, 4097)])
+def test_knn2_matches_oracle(nq, nr):
+    db = synth.random_descriptors(nr, 100 + nr)
+    q = synth.planted_queries(db, nq, 200 + nq, planted_frac=0.3 if nq >= 10 else 0.0)
+    if nr > 10:
+        db[nr // 2] = db[3]          # exact duplicate rows: the first index must win, second == best
+        q[0] = db[3]
+    m = capi.ORBmatcher()
+    got = _knn2(m, q, db)
+    ref = O.knn2(q, db)
+    for g, r, name in zip(got, ref, ("best_dist", "best_idx", "second_dist")):
+        assert np.array_equal(g, r), name
+
+
+def test_knn2_empty_reference_and_index_base():
+    m = capi.ORBmatcher()
+    q = synth.random_descriptors(5, 1)
+    bd, bi, sd = _knn2(m, q, np.zeros((0, 32), np.uint8))
+    assert (bd == 256).all() and (bi == -1).all() and (sd == 256).all()
+    db = synth.random_descriptors(500, 2)
+    a = _knn2(m, q, db, idx_base=1000)
+    b = O.knn2(q, db)
+    assert np.array_equal(a[1], b[1] + 1000) and np.array_equal(a[0], b[0])
+
+
+def test_knn2_sharded_merge_equals_unsharded():
+    db = synth.random_descriptors(30000, 77)
+    q = synth.planted_queries(db, 500, 78, planted_frac=0.2)
+    m = capi.ORBmatcher()
+    ref = O.knn2(q, db)
+    bounds = np.linspace(0, len(db), 9).astype(int)
+    parts = [_knn2(m, q, db[bounds[s]:bounds[s + 1]], idx_base=int(bounds[s])) for s in range(8)]
+    got = capi.merge_knn2(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), np.stack([p[2] for p in parts]))
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+
+
+def test_knn2_full_size_properties():
+    """BASELINE config 5 shard size (2000 x 125000): too slow for the scalar oracle, so check size-independent properties:
+    best <= second, returned distance equals the recomputed distance of the returned index, planted rows are found,
+    and a numpy column-chunked scan of a query subset agrees exactly."""
+    db = synth.random_descriptors(125000, 500)
+    q = synth.planted_queries(db, 2000, 501, planted_frac=0.1)
+    m = capi.ORBmatcher()
+    bd, bi, sd = _knn2(m, q, db)
+    assert (bd <= sd).all() and (bi >= 0).all()
+    recomputed = np.unpackbits(q ^ db[bi], axis=1).sum(1)
+    assert np.array_equal(recomputed, bd)
+    sub = np.arange(0, 2000, 125)
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for i in sub:
+        d = pop[q[i][None, :] ^ db].sum(1)
+        order = np.lexsort((np.arange(len(db)), d))
+        assert bd[i] == d[order[0]] and bi[i] == order[0] and sd[i] == d[order[1]]
+
+
+def test_csr_matches_oracle():
+    rng = np.random.default_rng(5)
+    r = synth.random_descriptors(3000, 9)
+    q = synth.planted_queries(r, 1500, 10, planted_frac=0.5)
+    counts = rng.integers(0, 50, 1500)
+    counts[:5] = 0                                  # empty candidate lists -> (256, -1, 256)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    idx = rng.integers(0, 3000, off[-1]).astype(np.int32)
+    m = capi.ORBmatcher()
+    dq, dr, doff, didx = _dev(q), _dev(r), _dev(off), _dev(idx)
+    bd, bi, sd = (torch.zeros(1500, dtype=torch.int32, device="cuda") for _ in range(3))
+    m.csr_device(dq.data_ptr(), 1500, dr.data_ptr(), 3000, doff.data_ptr(), didx.data_ptr(), bd.data_ptr(), bi.data_ptr(),
+                 sd.data_ptr())
+    ref = O.match_csr(q, r, off, idx)
+    for g, rr in zip((bd, bi, sd), ref):
+        assert np.array_equal(g.cpu().numpy(), rr)
+
+
+def test_stereo_rowband_matches_oracle():
+    left, right = synth.stereo_pair(1241, 376, synth.BASE_SEED + 50)
+    gl, gr = capi.ORBextractor(2000, 1.2, 8, 20, 7), capi.ORBextractor(2000, 1.2, 8, 20, 7)
+    kl, dl = gl(left)
+    kr, dr = gr(right)
+    ol, orr = O.OracleExtractor(2000, 1.2, 8, 20, 7), O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    kol, dol = ol.extract(left)
+    kor, dor = orr.extract(right)
+    assert np.array_equal(kl, kol) and np.array_equal(dr, dor)
+    sf = gl.GetScaleFactors()
+    bf, b = 386.1448, 0.5371657                      # KITTI00-02.yaml: Camera.bf, bf / fx(718.856)
+    max_d = np.float32(bf) / np.float32(b)
+    ref_bd, ref_bi = O.stereo_rowband(kl, dl, kr, dr, sf, 376, 0.0, float(max_d))
+    m = capi.ORBmatcher()
+    dkl = _dev(kl.view(np.uint8).reshape(-1, 28))
+    dkr = _dev(kr.view(np.uint8).reshape(-1, 28))
+    ddl, ddr = _dev(dl), _dev(dr)
+    bd, bi = (torch.zeros(len(kl), dtype=torch.int32, device="cuda") for _ in range(2))
+    m.stereo_rowband_device(dkl.data_ptr(), ddl.data_ptr(), len(kl), dkr.data_ptr(), ddr.data_ptr(), len(kr), sf, 376, 0.0,
+                            float(max_d), bd.data_ptr(), bi.data_ptr())
+    assert np.array_equal(bd.cpu().numpy(), ref_bd)
+    assert np.array_equal(bi.cpu().numpy(), ref_bi)
+    assert (ref_bd < 75).sum() > 200                 # the synthetic pair really produces stereo matches
