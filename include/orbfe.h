@@ -121,6 +121,13 @@ typedef struct orbfe_profile {
     int64_t keypoints;                         /* keypoints kept */
 } orbfe_profile;
 int orbfe_set_profiling(orbfe_extractor *e, int enable);
+/* Where DistributeOctTree (src/ORBextractor.cc:539-763) runs.  DEVICE (default): one workgroup per (frame, level),
+ * nothing leaves HBM between FAST and the descriptors.  HOST: candidates are copied out, culled on host threads (one
+ * (frame, level) task each) and the kept keypoints copied back -- the arrangement BASELINE.json's north_star starts
+ * from; kept for A/B measurement and used automatically when a level's quota exceeds the device kernel's node table
+ * (nfeatures beyond ~4700 at scale 1.2).  Both give identical results. */
+enum { ORBFE_QUADTREE_DEVICE = 0, ORBFE_QUADTREE_HOST = 1 };
+int orbfe_set_quadtree_mode(orbfe_extractor *e, int mode);
 int orbfe_get_profile(const orbfe_extractor *e, orbfe_profile *out);
 
 /* ------------------------------------------------------------------ ORBmatcher --------------------------- */

@@ -25,7 +25,7 @@ EXPORTS = [
     "orbfe_extract", "orbfe_extract_batch", "orbfe_synchronize", "orbfe_pyramid_level", "orbfe_debug_stage",
     "orbfe_hamming", "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_match_knn2", "orbfe_match_csr",
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
-    "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile",
+    "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -91,6 +91,7 @@ def lib():
     L.orbfe_merge_knn2.argtypes = [i32p, i32p, i32p, C.c_int, C.c_int, i32p, i32p, i32p]
     L.orbfe_set_profiling.argtypes = [vp, C.c_int]
     L.orbfe_get_profile.argtypes = [vp, C.POINTER(OrbfeProfile)]
+    L.orbfe_set_quadtree_mode.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -179,6 +180,10 @@ class ORBextractor:
 
     def synchronize(self):
         check(self._L.orbfe_synchronize(self._h))
+
+    def set_quadtree_mode(self, mode: str):
+        """'device' (default) or 'host' -- where DistributeOctTree runs; identical results."""
+        check(self._L.orbfe_set_quadtree_mode(self._h, {"device": 0, "host": 1}[mode]))
 
     def set_profiling(self, enable: bool):
         check(self._L.orbfe_set_profiling(self._h, 1 if enable else 0))

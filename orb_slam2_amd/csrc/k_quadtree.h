@@ -1,0 +1,336 @@
+// k_quadtree.h -- N1: DistributeOctTree on the GPU, one workgroup per (frame, level) (gfx950).
+//
+// Replaces ORBextractor::DistributeOctTree / ExtractorNode::DivideNode (reference src/ORBextractor.cc:481-763).  The
+// reference splits std::list nodes one at a time; what its result depends on is (a) which nodes are split in which
+// pass and (b) the final list order.  Both are reproduced in pass form (the same formulation as quadtree_host.h):
+//   breadth pass (:606-665)   every node with > 1 point is split;
+//                             new list = reverse(children in creation order) ++ (single-point nodes, old order)
+//   size-ordered pass (:676-737) expandable nodes ranked by (point count desc, creation index desc) are split until the
+//                             list holds N nodes; new list = reverse(children) ++ (old list minus the split parents)
+// A node is a slot in the current list.  Points never move: each candidate carries its node's slot (in Cand::pad, in
+// place in HBM; every thread only ever re-reads the entries it wrote itself).  Per pass: LDS-atomic child histograms,
+// block-wide prefix sums for the new list order, relabel.  "Keep the best response per node, first wins" (:744-760) is an
+// LDS ds_max_u64 on (response << 32 | ~order) where order is the candidate's position in the reference's emission order
+// (cell row, cell column, y, x), recomputed from its coordinates -- so the unordered, atomically packed candidate array
+// of the FAST kernel needs no sorting.
+// Ties between equal-size nodes in the size-ordered pass: the reference compares heap addresses (:684); as in the
+// oracle they are ordered by creation index.
+#pragma once
+#include "common.h"
+
+namespace orbfe {
+
+struct QuadtreeArgs {
+    Geom g;
+    Cand *cand;              // [F][candFrameCap]; pad field is scratch
+    const int *levelCount;   // [F][kMaxLevels]
+    SelKp *sel;              // [F][selFrameCap]
+    int *selCount;           // [F][kMaxLevels]
+    int *status;             // [1]: bit 0 = candidate overflow, bit 1 = node table overflow
+};
+
+template <int MAXN>
+struct QtShared {
+    uint32_t boxLo[2][MAXN];        // x0 | y0 << 16
+    uint32_t boxHi[2][MAXN];        // x1 | y1 << 16
+    int cnt[2][MAXN];
+    int child[4 * MAXN];            // child point counts of the slots being split (atomic); later the ds_max_u64 keys
+    uint16_t cidx[4 * MAXN];        // creation index of each non-empty child
+    uint16_t stay[MAXN];            // new slot offset of the nodes that are not split
+    uint16_t rankOf[MAXN];          // size-ordered pass: rank of an expandable slot (0xFFFF otherwise)
+    uint16_t slotByRank[MAXN];
+    int gain[MAXN];                 // size-ordered pass: nodes added by splitting rank r (inclusive prefix after scan)
+    int scanTmp[8];
+    int vars[8];
+};
+
+// exclusive prefix sum over LDS ints v[0..m) (in place), returns the total; all 256 threads must call
+__device__ __forceinline__ int block_scan_excl(int *v, int m, int *scanTmp) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (m + 255) >> 8;
+    const int b = tid * per, e = min(b + per, m);
+    int s = 0;
+    for (int i = b; i < e; i++) s += v[i];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) scanTmp[wv] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int t = scanTmp[k];
+        if (k < wv) base += t;
+        total += t;
+    }
+    int run = base + inc - s;
+    for (int i = b; i < e; i++) {
+        const int t = v[i];
+        v[i] = run;
+        run += t;
+    }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int qt_quadrant(uint32_t lo, uint32_t hi, int x, int y, int *mx, int *my) {
+    const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
+    *mx = x0 + ((x1 - x0 + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)   (:483)
+    *my = y0 + ((y1 - y0 + 1) >> 1);
+    return (x < *mx ? 0 : 1) + (y < *my ? 0 : 2);   // n1,n2,n3,n4 (:515-525)
+}
+
+__device__ __forceinline__ void qt_child_box(uint32_t lo, uint32_t hi, int q, uint32_t *clo, uint32_t *chi) {
+    const int x0 = lo & 0xffff, y0 = lo >> 16, x1 = hi & 0xffff, y1 = hi >> 16;
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+    const int cx0 = (q & 1) ? mx : x0, cx1 = (q & 1) ? x1 : mx;
+    const int cy0 = (q & 2) ? my : y0, cy1 = (q & 2) ? y1 : my;
+    *clo = (uint32_t)cx0 | ((uint32_t)cy0 << 16);
+    *chi = (uint32_t)cx1 | ((uint32_t)cy1 << 16);
+}
+
+template <int MAXN>
+__global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
+    extern __shared__ __align__(16) uint8_t qt_lds_raw[];
+    QtShared<MAXN> &S = *reinterpret_cast<QtShared<MAXN> *>(qt_lds_raw);
+    const int tid = threadIdx.x;
+    const int lvl = blockIdx.x, f = blockIdx.y;
+    const LevelGeom &L = a.g.lv[lvl];
+    const int N = L.quota;
+    int *selCount = a.selCount + f * kMaxLevels + lvl;
+    int n = a.levelCount[f * kMaxLevels + lvl];
+    if (n > L.candCap) {
+        if (tid == 0) atomicOr(a.status, 1);
+        n = L.candCap;
+    }
+    if (n == 0) {
+        if (tid == 0) *selCount = 0;
+        return;
+    }
+    Cand *pts = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
+    const int height = (L.h - kEdge + 3) - kMinBorder;
+
+    // ---- roots (:543-585): root r = (int)(x / hX); empty roots are dropped, list order = ascending r
+    const int nIni = L.nIni;
+    for (int i = tid; i < nIni; i += 256) S.child[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        int r = (int)__fdiv_rn((float)pts[p].x, L.hX);
+        r = min(r, nIni - 1);
+        atomicAdd(&S.child[r], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int slot = 0;
+        for (int r = 0; r < nIni; r++) {
+            const int c = S.child[r];
+            S.stay[r] = (uint16_t)slot;
+            if (c == 0) continue;
+            const int x0 = (int)__fmul_rn(L.hX, (float)r), x1 = (int)__fmul_rn(L.hX, (float)(r + 1));
+            S.boxLo[0][slot] = (uint32_t)x0;
+            S.boxHi[0][slot] = (uint32_t)x1 | ((uint32_t)height << 16);
+            S.cnt[0][slot] = c;
+            slot++;
+        }
+        S.vars[0] = slot;
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        int r = (int)__fdiv_rn((float)pts[p].x, L.hX);
+        r = min(r, nIni - 1);
+        pts[p].pad = S.stay[r];
+    }
+    int cur = 0;
+    int Lc = S.vars[0];
+    __syncthreads();
+
+    bool sized = false;   // false: breadth passes, true: size-ordered passes
+    for (int iter = 0; iter < 64; iter++) {
+        const uint32_t *bLo = S.boxLo[cur], *bHi = S.boxHi[cur];
+        const int *cnt = S.cnt[cur];
+        // ---- child histograms of every expandable slot
+        for (int i = tid; i < 4 * Lc; i += 256) S.child[i] = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += 256) {
+            const Cand c = pts[p];
+            const int s = c.pad;
+            if (cnt[s] > 1) {
+                int mx, my;
+                const int q = qt_quadrant(bLo[s], bHi[s], c.x, c.y, &mx, &my);
+                atomicAdd(&S.child[4 * s + q], 1);
+            }
+        }
+        __syncthreads();
+
+        int rStar = 0x7fffffff;   // size-ordered: last rank that is split
+        if (sized) {
+            // ---- rank expandable slots by (count desc, slot asc) == (count, creation index) walked from the back
+            for (int s = tid; s < Lc; s += 256) {
+                int rk = 0xFFFF;
+                const int c = cnt[s];
+                if (c > 1) {
+                    rk = 0;
+                    for (int t = 0; t < Lc; t++) {
+                        const int ct = cnt[t];
+                        rk += (ct > 1) && (ct > c || (ct == c && t < s));
+                    }
+                    S.slotByRank[rk] = (uint16_t)s;
+                    const int ne = (S.child[4 * s] > 0) + (S.child[4 * s + 1] > 0) + (S.child[4 * s + 2] > 0) + (S.child[4 * s + 3] > 0);
+                    S.gain[rk] = ne - 1;
+                }
+                S.rankOf[s] = (uint16_t)rk;
+            }
+            if (tid == 0) S.vars[1] = 0x7fffffff;
+            __syncthreads();
+            int E = 0;   // number of expandable slots: they occupy ranks 0..E-1
+            for (int s = tid; s < Lc; s += 256) E += cnt[s] > 1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) E += __shfl_xor(E, o);
+            if ((tid & 63) == 0) S.scanTmp[4 + (tid >> 6)] = E;
+            __syncthreads();
+            E = S.scanTmp[4] + S.scanTmp[5] + S.scanTmp[6] + S.scanTmp[7];
+            block_scan_excl(S.gain, E, S.scanTmp);   // gain[r] = nodes added by ranks < r
+            for (int r = tid; r < E; r += 256) {
+                const int s = S.slotByRank[r];
+                const int ne = (S.child[4 * s] > 0) + (S.child[4 * s + 1] > 0) + (S.child[4 * s + 2] > 0) + (S.child[4 * s + 3] > 0);
+                if (Lc + S.gain[r] + ne - 1 >= N) atomicMin(&S.vars[1], r);   // list reaches N after splitting rank r (:730)
+            }
+            __syncthreads();
+            rStar = min(S.vars[1], E - 1);
+            __syncthreads();
+        }
+
+        // ---- creation order of the children.  breadth: parents in list order; size-ordered: parents in rank order
+        //      cidx is indexed by 4*slot+q in both cases; the scan runs over the creation sequence.
+        //      Use S.gain as the scan scratch is not possible (needed above), so scan in S.child's shadow: cidx via ints
+        //      in a temporary view of `stay`/... -> keep it simple: scan over an int array aliased on the next box buffer.
+        int *scanBuf = reinterpret_cast<int *>(S.boxLo[cur ^ 1]);   // 4*MAXN bytes = MAXN ints: not enough for 4*Lc flags
+        (void)scanBuf;
+        // flags are packed per parent: nonempty-children count (0..4) per creation position, then expanded per child
+        int *perParent = S.cnt[cur ^ 1];   // MAXN ints, free until the new generation is written
+        const int nPar = sized ? (rStar + 1) : Lc;
+        for (int i = tid; i < nPar; i += 256) {
+            const int s = sized ? (int)S.slotByRank[i] : i;
+            int ne = 0;
+            if (cnt[s] > 1)
+                ne = (S.child[4 * s] > 0) + (S.child[4 * s + 1] > 0) + (S.child[4 * s + 2] > 0) + (S.child[4 * s + 3] > 0);
+            perParent[i] = ne;
+        }
+        __syncthreads();
+        const int C = block_scan_excl(perParent, nPar, S.scanTmp);
+        int nExp = 0;
+        for (int i = tid; i < nPar; i += 256) {
+            const int s = sized ? (int)S.slotByRank[i] : i;
+            if (cnt[s] > 1) {
+                int k = perParent[i];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int c = S.child[4 * s + q];
+                    if (c > 0) S.cidx[4 * s + q] = (uint16_t)k++;
+                    nExp += c > 1;
+                }
+            }
+        }
+        // ---- nodes that stay: single-point nodes (breadth) / everything not split (size-ordered), old order
+        int *stayFlag = S.gain;   // free again
+        for (int s = tid; s < Lc; s += 256) {
+            const bool split = sized ? (S.rankOf[s] <= rStar) : (cnt[s] > 1);
+            stayFlag[s] = split ? 0 : 1;
+        }
+        __syncthreads();
+        const int K = block_scan_excl(stayFlag, Lc, S.scanTmp);
+        const int newL = C + K;
+        if (newL > MAXN) {   // cannot happen for quota+3 <= MAXN; refuse rather than corrupt LDS
+            if (tid == 0) { atomicOr(a.status, 2); *selCount = 0; }
+            return;
+        }
+        // count expandable children (breadth pass decision :673)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nExp += __shfl_xor(nExp, o);
+        if ((tid & 63) == 0) S.scanTmp[4 + (tid >> 6)] = nExp;
+        // ---- relabel the points
+        for (int p = tid; p < n; p += 256) {
+            const Cand c = pts[p];
+            const int s = c.pad;
+            const bool split = sized ? (S.rankOf[s] <= rStar) : (cnt[s] > 1);
+            int ns;
+            if (split) {
+                int mx, my;
+                const int q = qt_quadrant(bLo[s], bHi[s], c.x, c.y, &mx, &my);
+                ns = C - 1 - S.cidx[4 * s + q];
+            } else {
+                ns = C + stayFlag[s];
+            }
+            pts[p].pad = (uint16_t)ns;
+        }
+        // ---- write the next generation
+        uint32_t *nLo = S.boxLo[cur ^ 1], *nHi = S.boxHi[cur ^ 1];
+        __syncthreads();   // perParent (aliases cnt[cur^1]) fully consumed before it is overwritten
+        int *nCnt = S.cnt[cur ^ 1];
+        for (int s = tid; s < Lc; s += 256) {
+            const bool split = sized ? (S.rankOf[s] <= rStar) : (cnt[s] > 1);
+            if (split) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int c = S.child[4 * s + q];
+                    if (c > 0) {
+                        const int ns = C - 1 - S.cidx[4 * s + q];
+                        uint32_t lo, hi;
+                        qt_child_box(bLo[s], bHi[s], q, &lo, &hi);
+                        nLo[ns] = lo;
+                        nHi[ns] = hi;
+                        nCnt[ns] = c;
+                    }
+                }
+            } else {
+                const int ns = C + stayFlag[s];
+                nLo[ns] = bLo[s];
+                nHi[ns] = bHi[s];
+                nCnt[ns] = cnt[s];
+            }
+        }
+        __syncthreads();
+        nExp = S.scanTmp[4] + S.scanTmp[5] + S.scanTmp[6] + S.scanTmp[7];
+        const int prevL = Lc;
+        Lc = newL;
+        cur ^= 1;
+        __syncthreads();
+        // ---- stop / switch rule (:669-673, :734)
+        if (Lc >= N || Lc == prevL) break;
+        if (!sized && Lc + 3 * nExp > N) sized = true;
+    }
+
+    // ---- best response per node, first in reference order wins (:744-760)
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(S.child);
+    for (int i = tid; i < Lc; i += 256) best[i] = 0ull;
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        const Cand c = pts[p];
+        // reference emission order: cell row, cell column, then row-major inside the cell (src/ORBextractor.cc:789-829)
+        const int ci = (c.y - 3) / L.hCell, cj = (c.x - 3) / L.wCell;
+        const int yin = c.y - 3 - ci * L.hCell, xin = c.x - 3 - cj * L.wCell;
+        const uint32_t order = ((uint32_t)(ci * L.nCols + cj) << 12) | ((uint32_t)yin << 6) | (uint32_t)xin;
+        const unsigned long long key = ((unsigned long long)(c.resp + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
+        atomicMax(&best[c.pad], key);
+    }
+    __syncthreads();
+    SelKp *out = a.sel + (size_t)f * a.g.selFrameCap + L.selOff;
+    for (int i = tid; i < Lc && i < L.selCap; i += 256) {
+        const unsigned long long key = best[i];
+        const uint32_t order = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+        const int cell = order >> 12, yin = (order >> 6) & 63, xin = order & 63;
+        const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+        SelKp k;
+        k.x = (uint16_t)(cj * L.wCell + 3 + xin + kMinBorder);   // += minBorderX (:843)
+        k.y = (uint16_t)(ci * L.hCell + 3 + yin + kMinBorder);
+        k.resp = (uint16_t)((key >> 32) - 1);
+        k.level = (uint16_t)lvl;
+        out[i] = k;
+    }
+    if (tid == 0) *selCount = min(Lc, L.selCap);
+}
+
+}  // namespace orbfe

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include "k_fast.h"
 #include "k_match.h"
 #include "k_pyramid.h"
+#include "k_quadtree.h"
 #include "quadtree_host.h"
 
 using namespace orbfe;
@@ -114,8 +116,11 @@ struct orbfe_extractor {
     // last call (for orbfe_pyramid_level / orbfe_debug_stage)
     ImgSrc last{};
     int lastFrames = 0;
-    std::vector<std::vector<Cand>> lastOrdered;   // [frame*nlevels + level] candidates in reference order
     bool overflow = false;
+    int quadtreeMode = ORBFE_QUADTREE_DEVICE;   // orbfe_set_quadtree_mode
+    bool lastOnHost = false;                    // did the last call bring candidates / kept keypoints to the host
+    DevBuf dStatus;
+    PinBuf hStatus;
     // optional per-stage timing with HIP events on the handle's stream (orbfe_set_profiling)
     bool profiling = false;
     hipEvent_t ev[8] = {};
@@ -225,8 +230,9 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
                                                "plus borders (the reference divides by zero there)");
         L.wCell = (int)std::ceil(width / L.nCols);
         L.hCell = (int)std::ceil(height / L.nRows);
-        if (L.wCell + 6 > kFastMaxWin || L.hCell + 6 > kFastMaxWin || L.wCell > 64)
+        if (L.wCell + 6 > kFastMaxWin || L.hCell + 6 > kFastMaxWin || L.wCell > 64 || L.hCell > 64)
             return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell larger than the kernel's LDS window");
+        if ((long)L.nCols * L.nRows >= (1 << 20)) return fail(ORBFE_ERR_UNSUPPORTED, "more than 2^20 FAST cells on a level");
         L.cellBase = cellBase;
         cellBase += L.nCols * L.nRows;
         const int detArea = std::max(1, (L.w - 2 * kEdge) * (L.h - 2 * kEdge));
@@ -304,6 +310,8 @@ int ensure_workspace(orbfe_extractor *e, int F) {
     HIPCHK(e->hCellTab.ensure((size_t)F * g.totalCells * sizeof(int2)));
     HIPCHK(e->hSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
     HIPCHK(e->hSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
+    HIPCHK(e->dStatus.ensure(16));
+    HIPCHK(e->hStatus.ensure(16));
     return ORBFE_OK;
 }
 
@@ -318,6 +326,72 @@ void ordered_candidates(const orbfe_extractor *e, int f, int l, std::vector<Cand
         const int off = tab[c].x, n = tab[c].y;
         for (int k = 0; k < n && off + k < L.candCap; k++) out.push_back(cand[off + k]);
     }
+}
+
+constexpr int kQtMaxNodes = 1024;   // live quadtree nodes the device kernel's LDS tables hold
+
+// The device quadtree needs max(quota+3, 4*nIni) <= kQtMaxNodes on every level; larger quotas (nfeatures beyond ~4700 at
+// scale 1.2) use the host quadtree, as does an explicit orbfe_set_quadtree_mode(ORBFE_QUADTREE_HOST).
+bool quadtree_on_host(const orbfe_extractor *e) {
+    if (e->quadtreeMode == ORBFE_QUADTREE_HOST) return true;
+    for (int l = 0; l < e->g.nlevels; l++)
+        if (std::max(e->g.lv[l].quota + 3, 4 * e->g.lv[l].nIni) > kQtMaxNodes || e->g.lv[l].nIni > 64) return true;
+    return false;
+}
+
+// candidates to the host, DistributeOctTree on host threads (one (frame, level) task each), kept keypoints back
+int host_quadtree_stage(orbfe_extractor *e, int F) {
+    const Geom &g = e->g;
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->hCellTab.p, e->dCellTab.p, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->hCand.p, e->dCand.p, (size_t)F * g.candFrameCap * sizeof(Cand), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    auto t0 = std::chrono::steady_clock::now();
+    {
+        const int *lc = (const int *)e->hLevelCount.p;
+        for (int f = 0; f < F; f++)
+            for (int l = 0; l < g.nlevels; l++)
+                if (lc[f * kMaxLevels + l] > g.lv[l].candCap) e->overflow = true;
+    }
+    const int tasks = F * g.nlevels;
+    int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nthreads = std::min(nthreads, tasks);
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        QuadtreeHost qt;
+        std::vector<Cand> kept, ordered;
+        for (;;) {
+            const int t = next.fetch_add(1);
+            if (t >= tasks) break;
+            const int f = t / g.nlevels, l = t % g.nlevels;
+            const LevelGeom &L = g.lv[l];
+            ordered_candidates(e, f, l, ordered);
+            const int width = (L.w - kEdge + 3) - kMinBorder, height = (L.h - kEdge + 3) - kMinBorder;
+            qt.run(ordered.data(), (int)ordered.size(), width, height, L.quota, L.nIni, L.hX, kept);
+            SelKp *sel = (SelKp *)e->hSel.p + (size_t)f * g.selFrameCap + L.selOff;
+            const int n = std::min((int)kept.size(), L.selCap);
+            for (int k = 0; k < n; k++) {
+                sel[k].x = (uint16_t)(kept[k].x + kMinBorder);   // :843-844
+                sel[k].y = (uint16_t)(kept[k].y + kMinBorder);
+                sel[k].resp = kept[k].resp;
+                sel[k].level = (uint16_t)l;
+            }
+            ((int *)e->hSelCount.p)[f * kMaxLevels + l] = n;
+        }
+    };
+    if (nthreads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
+    }
+    if (e->profiling)
+        e->stageMs[ORBFE_STAGE_QUADTREE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIPCHK(hipMemcpyAsync(e->dSel.p, e->hSel.p, (size_t)F * g.selFrameCap * sizeof(SelKp), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->dSelCount.p, e->hSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyHostToDevice, st));
+    return ORBFE_OK;
 }
 
 // The pipeline for F frames resident on the device.  Outputs on the device.
@@ -337,6 +411,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     src.blur = (uint8_t *)e->dBlur.p;
     e->last = src;
     e->lastFrames = F;
+    e->overflow = false;
 
     const bool prof = e->profiling;
     if (prof) HIPCHK(hipEventRecord(e->ev[0], st));
@@ -380,57 +455,24 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     if (prof) HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipGetLastError());
 
-    // candidates to the host, DistributeOctTree, kept keypoints back
-    HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(e->hCellTab.p, e->dCellTab.p, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(e->hCand.p, e->dCand.p, (size_t)F * g.candFrameCap * sizeof(Cand), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    e->overflow = false;
-    {
-        const int *lc = (const int *)e->hLevelCount.p;
-        for (int f = 0; f < F; f++)
-            for (int l = 0; l < g.nlevels; l++)
-                if (lc[f * kMaxLevels + l] > g.lv[l].candCap) e->overflow = true;
+    const bool hostTree = quadtree_on_host(e);
+    e->lastOnHost = hostTree;
+    HIPCHK(hipMemsetAsync(e->dStatus.p, 0, sizeof(int), st));
+    if (hostTree) {
+        rc = host_quadtree_stage(e, F);
+        if (rc) return rc;
+    } else {
+        // N1: DistributeOctTree on the device, one workgroup per (frame, level); nothing leaves HBM
+        QuadtreeArgs a;
+        a.g = g;
+        a.cand = (Cand *)e->dCand.p;
+        a.levelCount = (const int *)e->dLevelCount.p;
+        a.sel = (SelKp *)e->dSel.p;
+        a.selCount = (int *)e->dSelCount.p;
+        a.status = (int *)e->dStatus.p;
+        hipLaunchKernelGGL(quadtree_kernel<kQtMaxNodes>, dim3(g.nlevels, F), dim3(256), sizeof(QtShared<kQtMaxNodes>), st, a);
+        HIPCHK(hipGetLastError());
     }
-    e->lastOrdered.assign((size_t)F * g.nlevels, std::vector<Cand>());
-    {
-        const int tasks = F * g.nlevels;
-        int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-        nthreads = std::min(nthreads, tasks);
-        std::atomic<int> next(0);
-        auto worker = [&]() {
-            QuadtreeHost qt;
-            std::vector<Cand> kept;
-            for (;;) {
-                const int t = next.fetch_add(1);
-                if (t >= tasks) break;
-                const int f = t / g.nlevels, l = t % g.nlevels;
-                const LevelGeom &L = g.lv[l];
-                std::vector<Cand> &ordered = e->lastOrdered[t];
-                ordered_candidates(e, f, l, ordered);
-                const int width = (L.w - kEdge + 3) - kMinBorder, height = (L.h - kEdge + 3) - kMinBorder;
-                qt.run(ordered.data(), (int)ordered.size(), width, height, L.quota, L.nIni, L.hX, kept);
-                SelKp *sel = (SelKp *)e->hSel.p + (size_t)f * g.selFrameCap + L.selOff;
-                const int n = std::min((int)kept.size(), L.selCap);
-                for (int k = 0; k < n; k++) {
-                    sel[k].x = (uint16_t)(kept[k].x + kMinBorder);   // :843-844
-                    sel[k].y = (uint16_t)(kept[k].y + kMinBorder);
-                    sel[k].resp = kept[k].resp;
-                    sel[k].level = (uint16_t)l;
-                }
-                ((int *)e->hSelCount.p)[f * kMaxLevels + l] = n;
-            }
-        };
-        if (nthreads <= 1) {
-            worker();
-        } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
-            for (auto &th : pool) th.join();
-        }
-    }
-    HIPCHK(hipMemcpyAsync(e->dSel.p, e->hSel.p, (size_t)F * g.selFrameCap * sizeof(SelKp), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->dSelCount.p, e->hSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyHostToDevice, st));
     // K4 + K6
     if (prof) HIPCHK(hipEventRecord(e->ev[4], st));
     {
@@ -448,15 +490,20 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     HIPCHK(hipGetLastError());
     if (prof) {
         HIPCHK(hipEventRecord(e->ev[5], st));
-        HIPCHK(hipEventSynchronize(e->ev[5]));
+        if (!hostTree)
+            HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(e->hSelCount.p, e->dSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1])); e->stageMs[ORBFE_STAGE_PYRAMID] += ms;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); e->stageMs[ORBFE_STAGE_FAST] += ms;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); e->stageMs[ORBFE_STAGE_BLUR] += ms;
+        if (!hostTree) { HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); e->stageMs[ORBFE_STAGE_QUADTREE] += ms; }
         HIPCHK(hipEventElapsedTime(&ms, e->ev[4], e->ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
         e->stageLaunches[ORBFE_STAGE_PYRAMID] += g.nlevels - 1;
         e->stageLaunches[ORBFE_STAGE_FAST] += 1;
         e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
+        e->stageLaunches[ORBFE_STAGE_QUADTREE] += 1;
         e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
         e->stageFrames += F;
         const int *lc = (const int *)e->hLevelCount.p, *sc = (const int *)e->hSelCount.p;
@@ -541,9 +588,9 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
-                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
+                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->dStatus})
         b->release();
-    for (PinBuf *b : {&e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts})
+    for (PinBuf *b : {&e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
         b->release();
     delete e;
     return ORBFE_OK;
@@ -566,10 +613,29 @@ int orbfe_get_tables(const orbfe_extractor *e, float *scale, float *inv_scale, f
 
 void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream : nullptr; }
 
+// after the stream has drained: fold the device status word (device quadtree) into the handle
+static int fetch_status(orbfe_extractor *e) {
+    if (!e->dStatus.p || e->lastFrames == 0) return ORBFE_OK;
+    HIPCHK(hipMemcpyAsync(e->hStatus.p, e->dStatus.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int st = *(const int *)e->hStatus.p;
+    if (st & 1) e->overflow = true;
+    if (st & 2) return fail(ORBFE_ERR_CAPACITY, "quadtree node table overflow");
+    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
+    return ORBFE_OK;
+}
+
 int orbfe_synchronize(orbfe_extractor *e) {
     if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return fetch_status(e);
+}
+
+int orbfe_set_quadtree_mode(orbfe_extractor *e, int mode) {
+    if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
+    if (mode != ORBFE_QUADTREE_DEVICE && mode != ORBFE_QUADTREE_HOST) return fail(ORBFE_ERR_ARG, "unknown quadtree mode");
+    e->quadtreeMode = mode;
     return ORBFE_OK;
 }
 
@@ -584,8 +650,10 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
     HIPCHK(hipSetDevice(e->device));
     int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap);
     if (rc) return rc;
-    if (sync) HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
+    if (sync) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return fetch_status(e);
+    }
     return ORBFE_OK;
 }
 
@@ -616,7 +684,8 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
     HIPCHK(hipStreamSynchronize(e->stream));
     const int n = *(int *)e->hCounts.p;
     if (n_out) *n_out = n;
-    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
+    rc = fetch_status(e);
+    if (rc) return rc;
     if (n > cap) return fail(ORBFE_ERR_CAPACITY, "keypoint buffer too small");
     if (n == 0) return ORBFE_OK;
     if (!kps || !desc32) return fail(ORBFE_ERR_ARG, "null output");
@@ -680,7 +749,15 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
         return ORBFE_OK;
     }
     if (what == 2) {
-        const std::vector<Cand> &c = e->lastOrdered[(size_t)frame * g.nlevels + level];
+        // candidates in the reference's order: read the level's dense array + cell table back and walk the cells
+        const int F = e->lastFrames;
+        HIPCHK(hipMemcpy(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(e->hCellTab.p, e->dCellTab.p, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy((Cand *)e->hCand.p + (size_t)frame * g.candFrameCap + L.candOff,
+                         (const Cand *)e->dCand.p + (size_t)frame * g.candFrameCap + L.candOff, (size_t)L.candCap * sizeof(Cand),
+                         hipMemcpyDeviceToHost));
+        std::vector<Cand> c;
+        ordered_candidates(e, frame, level, c);
         const size_t need = c.size() * 3 * sizeof(float);
         if (bytes) *bytes = need;
         if (!dst || dst_bytes < need) return ORBFE_OK;
@@ -691,11 +768,15 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
         return ORBFE_OK;
     }
     if (what == 3) {
-        const int n = ((const int *)e->hSelCount.p)[frame * kMaxLevels + level];
+        int n = 0;
+        HIPCHK(hipMemcpy(&n, (const int *)e->dSelCount.p + frame * kMaxLevels + level, sizeof(int), hipMemcpyDeviceToHost));
         const size_t need = (size_t)n * 4 * sizeof(float);
         if (bytes) *bytes = need;
         if (!dst || dst_bytes < need) return ORBFE_OK;
-        const SelKp *sel = (const SelKp *)e->hSel.p + (size_t)frame * g.selFrameCap + L.selOff;
+        std::vector<SelKp> sel(n);
+        if (n)
+            HIPCHK(hipMemcpy(sel.data(), (const SelKp *)e->dSel.p + (size_t)frame * g.selFrameCap + L.selOff, (size_t)n * sizeof(SelKp),
+                             hipMemcpyDeviceToHost));
         float *o = (float *)dst;
         for (int i = 0; i < n; i++) {
             o[4 * i] = (float)sel[i].x; o[4 * i + 1] = (float)sel[i].y; o[4 * i + 2] = (float)sel[i].resp; o[4 * i + 3] = -1.f;

@@ -32,9 +32,11 @@ def test_tables_match_oracle():
         assert np.array_equal(tg[k], to[k]), k
 
 
+@pytest.mark.parametrize("mode", ["device", "host"])
 @pytest.mark.parametrize("cfg", ["kitti", "tum", "euroc"])
-def test_stagewise_parity(cfg):
+def test_stagewise_parity(cfg, mode):
     img, g, o = _pair(cfg, 3)
+    g.set_quadtree_mode(mode)
     kg, dg = g(img)
     ko, do = o.extract(img)
     for l in range(8):
@@ -56,6 +58,22 @@ def test_stagewise_parity(cfg):
     assert np.array_equal(kg["angle"], ko["angle"])
     nbits = int(np.unpackbits(dg ^ do).sum())
     assert nbits == 0, f"{nbits} descriptor bits differ"
+
+
+def test_quadtree_quota_sweep():
+    """Small and large quotas drive the quadtree through its different stop rules (N < 4*nIni, breadth-only, size-ordered)."""
+    img = synth.textured_image(1241, 376, synth.BASE_SEED + 30)
+    for nf in (8, 40, 150, 500, 1000, 3000, 4500):
+        g = capi.ORBextractor(nf, 1.2, 8, 20, 7)
+        o = O.OracleExtractor(nf, 1.2, 8, 20, 7)
+        kg, dg = g(img)
+        ko, do = o.extract(img)
+        assert np.array_equal(kg, ko) and np.array_equal(dg, do), nf
+    g = capi.ORBextractor(6000, 1.2, 8, 20, 7)      # quota beyond the device node table: host quadtree takes over
+    o = O.OracleExtractor(6000, 1.2, 8, 20, 7)
+    kg, dg = g(img)
+    ko, do = o.extract(img)
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
 
 
 def test_end_to_end_many_frames():
