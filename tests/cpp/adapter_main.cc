@@ -1,0 +1,39 @@
+// adapter_main.cc -- exercises ORB_SLAM2::ORBextractor (include/ORBextractor.h + adapters/ORBextractor_orbfe.cc) the way
+// Frame::ExtractORB does (reference src/Frame.cc:247-253), on a raw 8-bit image file, and dumps the outputs so the
+// pytest driver can compare them with the oracle.  usage: adapter_main in.raw w h nfeatures out.bin
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "ORBmatcher_orbfe.h"
+
+int main(int argc, char **argv) {
+    if (argc < 6) return 2;
+    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), nf = std::atoi(argv[4]);
+    std::vector<unsigned char> buf((size_t)w * h);
+    FILE *fi = std::fopen(argv[1], "rb");
+    if (!fi || std::fread(buf.data(), 1, buf.size(), fi) != buf.size()) return 3;
+    std::fclose(fi);
+    cv::Mat im(h, w, CV_8UC1, buf.data(), (size_t)w);
+    ORB_SLAM2::ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat desc;
+    ex(im, cv::Mat(), keys, desc);
+    FILE *fo = std::fopen(argv[5], "wb");
+    if (!fo) return 4;
+    int n = (int)keys.size();
+    std::fwrite(&n, 4, 1, fo);
+    std::fwrite(keys.data(), sizeof(cv::KeyPoint), n, fo);
+    for (int i = 0; i < n; i++) std::fwrite(desc.ptr(i), 1, 32, fo);
+    // mvImagePyramid[3]: ROI view + border, as Frame::ComputeStereoMatches reads it
+    const cv::Mat &p = ex.mvImagePyramid[3];
+    std::fwrite(&p.cols, 4, 1, fo);
+    std::fwrite(&p.rows, 4, 1, fo);
+    for (int y = -19; y < p.rows + 19; y++) std::fwrite(p.data + (long)y * (long)p.step - 19, 1, p.cols + 38, fo);
+    int d = orbfe_DescriptorDistance(desc.roi(0, 0, 32, 1), desc.roi(0, 1, 32, 1));
+    std::fwrite(&d, 4, 1, fo);
+    std::fclose(fo);
+    std::printf("adapter ok: %d keypoints, levels %d, scale %.3f\n", n, ex.GetLevels(), ex.GetScaleFactor());
+    return 0;
+}

@@ -1,0 +1,37 @@
+"""The C++ adapter (include/ORBextractor.h + adapters/ORBextractor_orbfe.cc: the reference's class interface on the
+C-ABI), driven like Frame::ExtractORB by tests/cpp/adapter_main, must reproduce the oracle bit for bit."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from orb_slam2_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_cpp_adapter_matches_oracle(tmp_path):
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    assert exe.exists(), "build it with make -C orb_slam2_amd/csrc (done by __graft_entry__.build())"
+    w, h, nf = 752, 480, 1200
+    img = synth.textured_image(w, h, synth.BASE_SEED + 60)
+    raw, out = tmp_path / "in.raw", tmp_path / "out.bin"
+    raw.write_bytes(img.tobytes())
+    r = subprocess.run([str(exe), str(raw), str(w), str(h), str(nf), str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    n = int(np.frombuffer(buf, np.int32, 1)[0])
+    kps = np.frombuffer(buf, capi.KP_DTYPE, n, 4)
+    desc = np.frombuffer(buf, np.uint8, n * 32, 4 + 28 * n).reshape(n, 32)
+    o = O.OracleExtractor(nf, 1.2, 8, 20, 7)
+    ko, do = o.extract(img)
+    assert n == len(ko) and np.array_equal(kps, ko) and np.array_equal(desc, do)
+    off = 4 + 60 * n
+    pw, ph = np.frombuffer(buf, np.int32, 2, off)
+    lvl = np.frombuffer(buf, np.uint8, (pw + 38) * (ph + 38), off + 8).reshape(ph + 38, pw + 38)
+    assert np.array_equal(lvl, np.pad(o.level(3), 19, mode="reflect"))
+    d01 = int(np.frombuffer(buf, np.int32, 1, off + 8 + (pw + 38) * (ph + 38))[0])
+    assert d01 == O.hamming(do[0], do[1])
