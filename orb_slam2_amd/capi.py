@@ -11,7 +11,9 @@ from pathlib import Path
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "liborbfe.so"
+import os as _os
+
+LIB_PATH = Path(_os.environ.get("ORBFE_LIB", PKG / "liborbfe.so"))   # ORBFE_LIB: A/B builds during kernel work
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -117,11 +119,15 @@ class ORBextractor:
         check(self._L.orbfe_extractor_create(C.byref(p), int(device), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.orbfe_extractor_destroy(self._h)
-            self._h = vp()
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value and getattr(self, "_L", None) is not None:
+            self._L.orbfe_extractor_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: module globals may already be gone
+            pass
 
     # ---- getters (include/ORBextractor.h:63-83)
     def GetLevels(self):
@@ -237,11 +243,15 @@ class ORBmatcher:
         check(self._L.orbfe_matcher_create(int(device), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.orbfe_matcher_destroy(self._h)
-            self._h = vp()
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value and getattr(self, "_L", None) is not None:
+            self._L.orbfe_matcher_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def DescriptorDistance(a: np.ndarray, b: np.ndarray) -> int:

@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     if (lvl < 0 || i >= a.cap) return;
     const LevelGeom &L = a.g.lv[lvl];
     const SelKp kp = a.sel[(size_t)f * a.g.selFrameCap + L.selOff + j];
-    const int cx = kp.x, cy = kp.y;
+    // keypoints lie in [19, w-20] x [19, h-20] by construction; the clamp only makes a corrupted entry harmless (no
+    // out-of-bounds gather) instead of a GPU fault
+    const int cx = min(max((int)kp.x, kEdge), L.w - kEdge - 1), cy = min(max((int)kp.y, kEdge), L.h - kEdge - 1);
 
     // ---- IC_Angle on the un-blurred level
     int pitch;

@@ -106,7 +106,8 @@ struct orbfe_extractor {
     std::vector<RszTab> hRsz;           // all levels' x and y tables
     std::vector<int> rszLdsPitch, rszLdsRows;
     std::vector<BlurTile> hBlurTiles;
-    DevBuf dRsz, dBlurTiles;
+    std::vector<FastTile> hFastTiles;
+    DevBuf dRsz, dBlurTiles, dFastTiles;
     // per-batch workspace
     DevBuf dPyr, dBlur, dCand, dLevelCount, dCellTab, dSel, dSelCount;
     PinBuf hCand, hLevelCount, hCellTab, hSel, hSelCount;
@@ -206,6 +207,7 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
     g.h0 = h;
     e->hRsz.clear();
     e->hBlurTiles.clear();
+    e->hFastTiles.clear();
     e->rszLdsPitch.assign(nl, 0);
     e->rszLdsRows.assign(nl, 0);
     int pyrOff = 0, blurOff = 0, cellBase = 0, candOff = 0, selOff = 0;
@@ -230,9 +232,22 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
                                                "plus borders (the reference divides by zero there)");
         L.wCell = (int)std::ceil(width / L.nCols);
         L.hCell = (int)std::ceil(height / L.nRows);
-        if (L.wCell + 6 > kFastMaxWin || L.hCell + 6 > kFastMaxWin || L.wCell > 64 || L.hCell > 64)
-            return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell larger than the kernel's LDS window");
-        if ((long)L.nCols * L.nRows >= (1 << 20)) return fail(ORBFE_ERR_UNSUPPORTED, "more than 2^20 FAST cells on a level");
+        if (L.wCell > 64 || L.hCell > 64)   // cannot happen for 30-px cells (wCell < 60), kept as a guard for the select kernel
+            return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell wider than a wavefront");
+        {
+            // FAST strips: whole cells per wavefront, at most 8 cells and 58 dword columns (+ 2 halo lanes each side)
+            L.fastCellsPerStrip = std::max(1, std::min(8, (4 * 58 - 3) / L.wCell));
+            const int nStrips = (L.nCols + L.fastCellsPerStrip - 1) / L.fastCellsPerStrip;
+            for (int i = 0; i < L.nRows; i++) {
+                if (kEdge + i * L.hCell >= L.h - kEdge) continue;
+                for (int sidx = 0; sidx < nStrips; sidx++) {
+                    if (kEdge + sidx * L.fastCellsPerStrip * L.wCell >= L.w - kEdge) continue;
+                    FastTile t;
+                    t.level = (uint16_t)l; t.strip = (uint16_t)sidx; t.cellRow = (uint16_t)i; t.pad = 0;
+                    e->hFastTiles.push_back(t);
+                }
+            }
+        }
         L.cellBase = cellBase;
         cellBase += L.nCols * L.nRows;
         const int detArea = std::max(1, (L.w - 2 * kEdge) * (L.h - 2 * kEdge));
@@ -273,8 +288,8 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
             if ((size_t)maxNd * 4 * maxNr > 60000)
                 return fail(ORBFE_ERR_UNSUPPORTED, "scale factor too large for the resize kernel's LDS tile");
         }
-        for (int ty = 0; ty * kBlurTH < L.h; ty++)
-            for (int tx = 0; tx * kBlurTW < L.w; tx++) {
+        for (int ty = 0; ty * kBlurRows < L.h; ty++)
+            for (int tx = 0; tx * kBlurStripDw * 4 < L.w; tx++) {
                 BlurTile t;
                 t.level = (uint16_t)l; t.tx = (uint16_t)tx; t.ty = (uint16_t)ty; t.pad = 0;
                 e->hBlurTiles.push_back(t);
@@ -290,6 +305,9 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
         HIPCHK(hipMemcpyAsync(e->dRsz.p, e->hRsz.data(), e->hRsz.size() * sizeof(RszTab), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e->dBlurTiles.ensure(e->hBlurTiles.size() * sizeof(BlurTile)));
     HIPCHK(hipMemcpyAsync(e->dBlurTiles.p, e->hBlurTiles.data(), e->hBlurTiles.size() * sizeof(BlurTile),
+                          hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e->dFastTiles.ensure(e->hFastTiles.size() * sizeof(FastTile)));
+    HIPCHK(hipMemcpyAsync(e->dFastTiles.p, e->hFastTiles.data(), e->hFastTiles.size() * sizeof(FastTile),
                           hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->haveGeom = true;
@@ -437,27 +455,34 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     }
     // K3: FAST over every cell of every level
     HIPCHK(hipMemsetAsync(e->dLevelCount.p, 0, (size_t)F * kMaxLevels * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(e->dCellTab.p, 0, (size_t)F * g.totalCells * sizeof(int2), st));
+    HIPCHK(hipMemsetAsync(e->dStatus.p, 0, sizeof(int), st));
     if (prof) HIPCHK(hipEventRecord(e->ev[1], st));
     {
+        const int iniTh = std::min(std::max(e->p.ini_th_fast, 0), 255), minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
         FastArgs a;
         a.g = g; a.s = src;
+        a.tiles = (const FastTile *)e->dFastTiles.p;
+        a.nTiles = (int)e->hFastTiles.size();
         a.cand = (Cand *)e->dCand.p;
         a.levelCount = (int *)e->dLevelCount.p;
         a.cellTab = (int2 *)e->dCellTab.p;
-        a.iniTh = std::min(std::max(e->p.ini_th_fast, 0), 255);
-        a.minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
-        hipLaunchKernelGGL(fast_cells_kernel, dim3(g.totalCells, F), dim3(256), 0, st, a);
+        a.status = (int *)e->dStatus.p;
+        // iniTh < minTh would make the fallback a no-op in the reference too (FAST at the lower threshold runs first)
+        a.iniTh = std::max(iniTh, minTh);
+        a.minTh = std::min(iniTh, minTh);
+        if (iniTh < minTh) a.iniTh = a.minTh = iniTh;
+        hipLaunchKernelGGL(fast_cells_kernel, dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
     }
     if (prof) HIPCHK(hipEventRecord(e->ev[2], st));
     // K5: blur of every level
-    hipLaunchKernelGGL(gauss7_kernel, dim3((unsigned)e->hBlurTiles.size(), F), dim3(256), 0, st, g, src,
-                       (const BlurTile *)e->dBlurTiles.p);
+    hipLaunchKernelGGL(gauss7_kernel, dim3(((unsigned)e->hBlurTiles.size() + 3) / 4, F), dim3(256), 0, st, g, src,
+                       (const BlurTile *)e->dBlurTiles.p, (int)e->hBlurTiles.size());
     if (prof) HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipGetLastError());
 
     const bool hostTree = quadtree_on_host(e);
     e->lastOnHost = hostTree;
-    HIPCHK(hipMemsetAsync(e->dStatus.p, 0, sizeof(int), st));
     if (hostTree) {
         rc = host_quadtree_stage(e, F);
         if (rc) return rc;
@@ -501,7 +526,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         if (!hostTree) { HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); e->stageMs[ORBFE_STAGE_QUADTREE] += ms; }
         HIPCHK(hipEventElapsedTime(&ms, e->ev[4], e->ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
         e->stageLaunches[ORBFE_STAGE_PYRAMID] += g.nlevels - 1;
-        e->stageLaunches[ORBFE_STAGE_FAST] += 1;
+        e->stageLaunches[ORBFE_STAGE_FAST] += 1;   // score kernel + select kernel, timed together
         e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
         e->stageLaunches[ORBFE_STAGE_QUADTREE] += 1;
         e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
@@ -587,7 +612,7 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
     }
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
-    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
+    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->dStatus})
         b->release();
     for (PinBuf *b : {&e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
@@ -621,6 +646,7 @@ static int fetch_status(orbfe_extractor *e) {
     const int st = *(const int *)e->hStatus.p;
     if (st & 1) e->overflow = true;
     if (st & 2) return fail(ORBFE_ERR_CAPACITY, "quadtree node table overflow");
+    if (st & 4) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list of a strip overflowed (more than 2048 local maxima in 8 cells)");
     if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
     return ORBFE_OK;
 }

@@ -1,0 +1,90 @@
+// valu_rates.hip -- measured issue rates of the integer VALU instructions the orbfe kernels lean on (gfx950).
+// Each kernel runs ITERS x 64 instructions of one kind on 8 independent register chains; grid = 256 CUs x 4 SIMDs x W.
+// Prints wave-instructions per SIMD per cycle-equivalent: Gops/s (lane-ops) and cycles per wave-instruction per SIMD at
+// the nominal 2.4 GHz.  build: hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define ITERS 2000
+
+#define DEFKERNEL(name, ASM)                                                                      \
+    __global__ __launch_bounds__(256) void name(unsigned *out, unsigned seed) {                    \
+        unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13,     \
+                 a6 = a0 * 17, a7 = a0 * 19, b = seed * 2654435761u, c = seed + 12345;             \
+        for (int i = 0; i < ITERS; i++) {                                                          \
+            _Pragma("unroll") for (int j = 0; j < 8; j++) {                                        \
+                asm volatile(ASM("%0") "\n" ASM("%1") "\n" ASM("%2") "\n" ASM("%3") "\n"           \
+                             ASM("%4") "\n" ASM("%5") "\n" ASM("%6") "\n" ASM("%7")                \
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                             : "v"(b), "v"(c));                                                    \
+            }                                                                                      \
+        }                                                                                          \
+        out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;               \
+    }
+
+#define A_XOR(r) "v_xor_b32 " r ", " r ", %8"
+#define A_BCNT(r) "v_bcnt_u32_b32 " r ", %8, " r
+#define A_PKMAX(r) "v_pk_max_u16 " r ", " r ", %8"
+#define A_MAX3(r) "v_max3_u32 " r ", " r ", %8, %9"
+#define A_MAXU(r) "v_max_u32 " r ", " r ", %8"
+#define A_ALIGNB(r) "v_alignbyte_b32 " r ", " r ", %8, 1"
+#define A_PERM(r) "v_perm_b32 " r ", " r ", %8, %9"
+#define A_DOT4(r) "v_dot4_u32_u8 " r ", " r ", %8, %9"
+#define A_MED3(r) "v_med3_u32 " r ", " r ", %8, %9"
+#define A_MAD24(r) "v_mad_u32_u24 " r ", " r ", %8, %9"
+#define A_MULLO(r) "v_mul_lo_u32 " r ", " r ", %8"
+#define A_LSHLOR(r) "v_lshl_or_b32 " r ", " r ", 3, %8"
+#define A_ADD(r) "v_add_u32 " r ", " r ", %8"
+#define A_PKMUL(r) "v_pk_mul_lo_u16 " r ", " r ", %8"
+#define A_FMA(r) "v_fma_f32 " r ", " r ", %8, %9"
+
+DEFKERNEL(k_xor, A_XOR)
+DEFKERNEL(k_bcnt, A_BCNT)
+DEFKERNEL(k_pkmax, A_PKMAX)
+DEFKERNEL(k_max3, A_MAX3)
+DEFKERNEL(k_maxu, A_MAXU)
+DEFKERNEL(k_alignb, A_ALIGNB)
+DEFKERNEL(k_perm, A_PERM)
+DEFKERNEL(k_dot4, A_DOT4)
+DEFKERNEL(k_med3, A_MED3)
+DEFKERNEL(k_mad24, A_MAD24)
+DEFKERNEL(k_mullo, A_MULLO)
+DEFKERNEL(k_lshlor, A_LSHLOR)
+DEFKERNEL(k_add, A_ADD)
+DEFKERNEL(k_pkmul, A_PKMUL)
+DEFKERNEL(k_fma, A_FMA)
+
+typedef void (*kern_t)(unsigned *, unsigned);
+
+int main() {
+    unsigned *out;
+    hipMalloc(&out, 256 * 4 * 16 * 256 * sizeof(unsigned) * 4);
+    struct { const char *name; kern_t k; } ks[] = {
+        {"v_xor_b32", k_xor}, {"v_bcnt_u32_b32", k_bcnt}, {"v_pk_max_u16", k_pkmax}, {"v_max3_u32", k_max3},
+        {"v_max_u32", k_maxu}, {"v_alignbyte_b32", k_alignb}, {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4},
+        {"v_med3_u32", k_med3}, {"v_mad_u32_u24", k_mad24}, {"v_mul_lo_u32", k_mullo}, {"v_lshl_or_b32", k_lshlor},
+        {"v_add_u32", k_add}, {"v_pk_mul_lo_u16", k_pkmul}, {"v_fma_f32", k_fma}};
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int wavesPerSimd[] = {1, 2, 4, 8};
+    printf("%-18s %6s %12s %14s\n", "instruction", "w/SIMD", "Tlane-ops/s", "cyc/instr@2.4G");
+    for (auto &k : ks)
+        for (int w : wavesPerSimd) {
+            const int blocks = 256 * w;   // 256 threads = 4 waves = one per SIMD of a CU
+            hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, out, 1u);
+            hipDeviceSynchronize();
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, out, 2u);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double instrPerWave = (double)ITERS * 64;
+            const double laneOps = instrPerWave * 64.0 * blocks * 4;
+            const double cyc = (ms * 1e-3 * 2.4e9) / (instrPerWave * w);
+            printf("%-18s %6d %12.2f %14.2f\n", k.name, w, laneOps / (ms * 1e-3) / 1e12, cyc);
+        }
+    return 0;
+}
