@@ -30,7 +30,7 @@ struct DescribeArgs {
 // table with the reference's arithmetic at create time and refuses to run if it differs.
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "pattern31.inc"
 };
 
@@ -63,6 +63,39 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// sin and cos of x in [0, 2*pi] in double, good to ~1e-15 absolute: quadrant reduction with a two-term pi/2, then Taylor
+// polynomials on |r| <= pi/4 (remainders (pi/4)^17/17! and (pi/4)^16/16! are below 1e-16).  About 30 double operations
+// instead of the ~170 of the general-purpose library routine; every operation is an explicit fma/mul/add.
+__device__ __forceinline__ void sincos_0_2pi(double x, double *s, double *c) {
+    const double twoOverPi = 0.63661977236758134308, pio2Hi = 1.57079632679489655800e+00, pio2Lo = 6.12323399573676603587e-17;
+    const double qd = __builtin_rint(x * twoOverPi);
+    const int q = (int)qd;
+    double r = __builtin_fma(-qd, pio2Hi, x);
+    r = __builtin_fma(-qd, pio2Lo, r);
+    const double z = r * r;
+    double ps = -7.6471637318198164759e-13;                // -1/15!
+    ps = __builtin_fma(ps, z, 1.6059043836821614599e-10);  //  1/13!
+    ps = __builtin_fma(ps, z, -2.5052108385441718775e-08); // -1/11!
+    ps = __builtin_fma(ps, z, 2.7557319223985890653e-06);  //  1/9!
+    ps = __builtin_fma(ps, z, -1.9841269841269841270e-04); // -1/7!
+    ps = __builtin_fma(ps, z, 8.3333333333333333333e-03);  //  1/5!
+    ps = __builtin_fma(ps, z, -1.6666666666666666667e-01); // -1/3!
+    const double sr = __builtin_fma(ps * z, r, r);
+    double pc = 4.7794773323873852974e-14;                 //  1/16!
+    pc = __builtin_fma(pc, z, -1.1470745597729724714e-11); // -1/14!
+    pc = __builtin_fma(pc, z, 2.0876756987868098979e-09);  //  1/12!
+    pc = __builtin_fma(pc, z, -2.7557319223985890653e-07); // -1/10!
+    pc = __builtin_fma(pc, z, 2.4801587301587301587e-05);  //  1/8!
+    pc = __builtin_fma(pc, z, -1.3888888888888888889e-03); // -1/6!
+    pc = __builtin_fma(pc, z, 4.1666666666666666667e-02);  //  1/4!
+    pc = __builtin_fma(pc, z, -0.5);
+    const double cr = __builtin_fma(pc, z, 1.0);
+    // rotate by the quadrant
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -s0 : s0;
+    *c = ((q + 1) & 2) ? -c0 : c0;
+}
+
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.y;
@@ -83,21 +116,35 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     // out-of-bounds gather) instead of a GPU fault
     const int cx = min(max((int)kp.x, kEdge), L.w - kEdge - 1), cy = min(max((int)kp.y, kEdge), L.h - kEdge - 1);
 
-    // ---- IC_Angle on the un-blurred level
+    // ---- IC_Angle on the un-blurred level: the 31 disc rows are fetched as 31 x 9 aligned dwords (5 per lane, all
+    //      in flight together); each lane folds its own bytes into (m10, m01)
     int pitch;
     const uint8_t *img = level_ptr(a.s, a.g, f, lvl, &pitch);
+    const int xa = (cx - kHalfPatch) & ~3;   // >= 4; xa + 35 <= cx + 20 < pitch
+    uint32_t dwv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int it = lane + 64 * k;
+        const int row = it / 9, dc = it - row * 9;
+        dwv[k] = (it < 31 * 9) ? *reinterpret_cast<const uint32_t *>(img + (size_t)(cy - kHalfPatch + row) * pitch + xa + 4 * dc) : 0u;
+    }
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        const int v = lane - kHalfPatch;
-        const int d = c_umax[v < 0 ? -v : v];
-        const uint8_t *row = img + (size_t)(cy + v) * pitch + cx;
-        int s = 0;
-        for (int u = -d; u <= d; ++u) {
-            const int I = row[u];
-            m10 += u * I;
-            s += I;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int it = lane + 64 * k;
+        const int row = it / 9, dc = it - row * 9;
+        const int v = row - kHalfPatch;
+        const int dmax = (it < 31 * 9) ? c_umax[v < 0 ? -v : v] : -1;
+        int rs = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int u = xa + 4 * dc + b - cx;
+            const int I = (int)((dwv[k] >> (8 * b)) & 0xFFu);
+            const int Iin = (u >= -dmax && u <= dmax) ? I : 0;
+            m10 += u * Iin;
+            rs += Iin;
         }
-        m01 = v * s;
+        m01 += v * rs;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -106,14 +153,18 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     // ---- rBRIEF on the blurred level
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
-    const float ca = (float)cos((double)ang), sb = (float)sin((double)ang);
+    double sd, cd;
+    sincos_0_2pi((double)ang, &sd, &cd);
+    const float ca = (float)cd, sb = (float)sd;
     const uint8_t *blur = a.s.blur + (size_t)f * a.g.blurFrameBytes + L.blurOff + (size_t)cy * L.pitch + cx;
     const int bp = L.pitch;
     uint32_t nib = 0;
+    const uint32_t *pat32 = reinterpret_cast<const uint32_t *>(c_pattern);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const int8_t *pp = &c_pattern[(lane * 4 + t) * 4];
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const uint32_t pp = pat32[lane * 4 + t];   // (x0, y0, x1, y1) as int8
+        const float x0 = (float)(int8_t)(pp & 0xFF), y0 = (float)(int8_t)((pp >> 8) & 0xFF), x1 = (float)(int8_t)((pp >> 16) & 0xFF),
+                    y1 = (float)(int8_t)(pp >> 24);
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
