@@ -100,16 +100,19 @@ def main():
     ex = capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
 
     def step():
+        # asynchronous on the library's stream: the K steps queue back to back, as an offline extraction job would
         ex.extract_batch_device(frames.data_ptr(), B, W, H, stride, stride * H, kps.data_ptr(), desc.data_ptr(),
-                                cnt.data_ptr(), cap, sync=True)
+                                cnt.data_ptr(), cap, sync=False)
 
     for _ in range(args.warmup):
         step()
-    ex.set_profiling(True)
+    ex.synchronize()
+    ex.set_profiling(True)      # HIP events on the library's stream around every stage; never blocks the stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ex.synchronize()            # the library's own stream (torch.cuda.synchronize does not cover a non-blocking stream)
     barrier()
     dt = time.perf_counter() - t0
     prof = ex.profile()

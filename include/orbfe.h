@@ -109,8 +109,8 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
 
 /* Per-stage device timing of the extractor, taken with HIP events recorded on the handle's stream around each
  * stage's kernel launches inside orbfe_extract / orbfe_extract_batch (no counterpart in the reference, whose only
- * timing is the wall clock around TrackStereo in Examples/Stereo/stereo_kitti.cc:80-97).  Enabling resets the sums;
- * while enabled every call ends with an event synchronisation. */
+ * timing is the wall clock around TrackStereo in Examples/Stereo/stereo_kitti.cc:80-97).  Enabling resets the sums.
+ * Recording never blocks the stream; orbfe_get_profile drains the stream and folds the recorded events into the sums. */
 enum { ORBFE_STAGE_PYRAMID = 0, ORBFE_STAGE_FAST = 1, ORBFE_STAGE_BLUR = 2, ORBFE_STAGE_DESCRIBE = 3,
        ORBFE_STAGE_QUADTREE = 4, ORBFE_STAGE_COUNT = 5 };
 typedef struct orbfe_profile {
@@ -128,7 +128,7 @@ int orbfe_set_profiling(orbfe_extractor *e, int enable);
  * (nfeatures beyond ~4700 at scale 1.2).  Both give identical results. */
 enum { ORBFE_QUADTREE_DEVICE = 0, ORBFE_QUADTREE_HOST = 1 };
 int orbfe_set_quadtree_mode(orbfe_extractor *e, int mode);
-int orbfe_get_profile(const orbfe_extractor *e, orbfe_profile *out);
+int orbfe_get_profile(orbfe_extractor *e, orbfe_profile *out);
 
 /* ------------------------------------------------------------------ ORBmatcher --------------------------- */
 

@@ -124,7 +124,17 @@ struct orbfe_extractor {
     PinBuf hStatus;
     // optional per-stage timing with HIP events on the handle's stream (orbfe_set_profiling)
     bool profiling = false;
-    hipEvent_t ev[8] = {};
+    // profiling never blocks the stream: each call records one ProfSet; sets are folded into the sums when the profile is
+    // read (orbfe_get_profile), when profiling is switched, or when kMaxPendingProf sets are outstanding
+    struct ProfSet {
+        hipEvent_t ev[6] = {};
+        int *counts = nullptr;   // pinned: [2][F][kMaxLevels] (level counts, kept counts)
+        int F = 0, capF = 0, nlevels = 0;
+        bool hostTree = false;
+    };
+    std::vector<ProfSet> profPool;
+    size_t profPending = 0;
+    hipEvent_t *ev = nullptr;   // the set being recorded by the current call
     double stageMs[ORBFE_STAGE_COUNT] = {};
     long stageLaunches[ORBFE_STAGE_COUNT] = {};
     long stageFrames = 0;
@@ -412,6 +422,57 @@ int host_quadtree_stage(orbfe_extractor *e, int F) {
     return ORBFE_OK;
 }
 
+constexpr size_t kMaxPendingProf = 256;
+
+// fold every recorded-but-unread event set into the sums (drains the stream first)
+int prof_resolve(orbfe_extractor *e) {
+    if (e->profPending == 0) return ORBFE_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < e->profPending; i++) {
+        orbfe_extractor::ProfSet &p = e->profPool[i];
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[0], p.ev[1])); e->stageMs[ORBFE_STAGE_PYRAMID] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[1], p.ev[2])); e->stageMs[ORBFE_STAGE_FAST] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[2], p.ev[3])); e->stageMs[ORBFE_STAGE_BLUR] += ms;
+        if (!p.hostTree) { HIPCHK(hipEventElapsedTime(&ms, p.ev[3], p.ev[4])); e->stageMs[ORBFE_STAGE_QUADTREE] += ms; }
+        HIPCHK(hipEventElapsedTime(&ms, p.ev[4], p.ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
+        e->stageLaunches[ORBFE_STAGE_PYRAMID] += p.nlevels - 1;
+        e->stageLaunches[ORBFE_STAGE_FAST] += 1;
+        e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
+        e->stageLaunches[ORBFE_STAGE_QUADTREE] += 1;
+        e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
+        e->stageFrames += p.F;
+        const int *lc = p.counts, *sc = p.counts + (size_t)p.F * kMaxLevels;
+        for (int f = 0; f < p.F; f++)
+            for (int l = 0; l < p.nlevels; l++) { e->candTotal += lc[f * kMaxLevels + l]; e->kpTotal += sc[f * kMaxLevels + l]; }
+    }
+    e->profPending = 0;
+    return ORBFE_OK;
+}
+
+int prof_acquire(orbfe_extractor *e, int F, orbfe_extractor::ProfSet **out) {
+    if (e->profPending >= kMaxPendingProf) {
+        int rc = prof_resolve(e);
+        if (rc) return rc;
+    }
+    if (e->profPending >= e->profPool.size()) {
+        orbfe_extractor::ProfSet p;
+        for (auto &ev : p.ev) HIPCHK(hipEventCreate(&ev));
+        e->profPool.push_back(p);
+    }
+    orbfe_extractor::ProfSet &p = e->profPool[e->profPending];
+    if (p.capF < F) {
+        if (p.counts) (void)hipHostFree(p.counts);
+        p.counts = nullptr;
+        HIPCHK(hipHostMalloc((void **)&p.counts, (size_t)2 * F * kMaxLevels * sizeof(int), hipHostMallocDefault));
+        p.capF = F;
+    }
+    p.F = F;
+    p.nlevels = e->g.nlevels;
+    *out = &p;
+    return ORBFE_OK;
+}
+
 // The pipeline for F frames resident on the device.  Outputs on the device.
 int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int stride, size_t frameStride,
               orbfe_keypoint *dKps, uint8_t *dDesc, int32_t *dCounts, int cap) {
@@ -432,7 +493,13 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     e->overflow = false;
 
     const bool prof = e->profiling;
-    if (prof) HIPCHK(hipEventRecord(e->ev[0], st));
+    orbfe_extractor::ProfSet *ps = nullptr;
+    if (prof) {
+        rc = prof_acquire(e, F, &ps);
+        if (rc) return rc;
+        e->ev = ps->ev;
+        HIPCHK(hipEventRecord(e->ev[0], st));
+    }
     // K1: pyramid, level by level (level l reads level l-1)
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom &L = g.lv[l], &P = g.lv[l - 1];
@@ -515,25 +582,11 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     HIPCHK(hipGetLastError());
     if (prof) {
         HIPCHK(hipEventRecord(e->ev[5], st));
-        if (!hostTree)
-            HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(e->hSelCount.p, e->dSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1])); e->stageMs[ORBFE_STAGE_PYRAMID] += ms;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); e->stageMs[ORBFE_STAGE_FAST] += ms;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); e->stageMs[ORBFE_STAGE_BLUR] += ms;
-        if (!hostTree) { HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); e->stageMs[ORBFE_STAGE_QUADTREE] += ms; }
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[4], e->ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
-        e->stageLaunches[ORBFE_STAGE_PYRAMID] += g.nlevels - 1;
-        e->stageLaunches[ORBFE_STAGE_FAST] += 1;   // score kernel + select kernel, timed together
-        e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
-        e->stageLaunches[ORBFE_STAGE_QUADTREE] += 1;
-        e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
-        e->stageFrames += F;
-        const int *lc = (const int *)e->hLevelCount.p, *sc = (const int *)e->hSelCount.p;
-        for (int f = 0; f < F; f++)
-            for (int l = 0; l < g.nlevels; l++) { e->candTotal += lc[f * kMaxLevels + l]; e->kpTotal += sc[f * kMaxLevels + l]; }
+        ps->hostTree = hostTree;
+        HIPCHK(hipMemcpyAsync(ps->counts, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ps->counts + (size_t)F * kMaxLevels, e->dSelCount.p, (size_t)F * kMaxLevels * sizeof(int),
+                              hipMemcpyDeviceToHost, st));
+        e->profPending++;
     }
     return ORBFE_OK;
 }
@@ -576,17 +629,15 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         delete e;
         return fail(ORBFE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(er));
     }
-    for (auto &ev : e->ev)
-        if (hipEventCreate(&ev) != hipSuccess) {
-            delete e;
-            return fail(ORBFE_ERR_DEVICE, "hipEventCreate failed");
-        }
     *out = e;
     return ORBFE_OK;
 }
 
 int orbfe_set_profiling(orbfe_extractor *e, int enable) {
     if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = prof_resolve(e);
+    if (rc) return rc;
     e->profiling = enable != 0;
     for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; }
     e->stageFrames = 0;
@@ -594,8 +645,11 @@ int orbfe_set_profiling(orbfe_extractor *e, int enable) {
     return ORBFE_OK;
 }
 
-int orbfe_get_profile(const orbfe_extractor *e, orbfe_profile *out) {
+int orbfe_get_profile(orbfe_extractor *e, orbfe_profile *out) {
     if (!e || !out) return fail(ORBFE_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = prof_resolve(e);
+    if (rc) return rc;
     for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { out->stage_ms[i] = e->stageMs[i]; out->stage_launches[i] = e->stageLaunches[i]; }
     out->frames = e->stageFrames;
     out->candidates = e->candTotal;
@@ -610,8 +664,11 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamDestroy(e->stream);
     }
-    for (auto &ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &p : e->profPool) {
+        for (auto &ev : p.ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (p.counts) (void)hipHostFree(p.counts);
+    }
     for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->dStatus})
         b->release();
