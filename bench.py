@@ -173,11 +173,14 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             hdt = float(tt.item())
         pairs = NQ * shard * world * hsteps
-        lane_ops = pairs * 19 / hdt                   # 8 xor + 8 bcnt + 3 selection ops per pair
+        # integer-VALU roofline of the pair loop: 8 v_xor (full rate) + 8 v_bcnt + v_lshl_or + v_med3 + v_min (half rate).
+        # Rates measured on this chip by tools/ubench/valu_rates.hip (profiles/r1_valu_rates_ubench.txt):
+        # ~62 T lane-ops/s for v_xor/v_add, ~38 T lane-ops/s for v_bcnt / v_med3 / v_min / v_lshl_or.
+        peak_pairs = world / (8 / 62e12 + 11 / 38e12)
         hamming = {"metric": "hamming_pair_distances_per_sec", "value": round(pairs / hdt, 1), "ms_per_query_batch": round(hdt / hsteps * 1e3, 3),
                    "queries": NQ, "database": shard * world, "shards": world,
-                   "valu": {"achieved_Tlaneops": round(lane_ops / 1e12, 2), "peak_Tlaneops": 78.6 * world,
-                            "frac": round(lane_ops / 1e12 / (78.6 * world), 4)}}
+                   "valu": {"achieved_Tpairs": round(pairs / hdt / 1e12, 3), "peak_Tpairs": round(peak_pairs / 1e12, 3),
+                            "frac": round(pairs / hdt / peak_pairs, 4), "lane_ops_per_pair": 19}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -29,10 +29,25 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
     return max(min(a, b), min(max(a, b), c));   // folds to v_med3_u32
 }
 
+// v_bcnt_u32_b32 D = popcount(S0) + S1: the accumulate operand makes the 8-dword distance 8 XOR + 8 BCNT with no separate
+// adds.  hipcc re-associates `d += __popc(x)` into bcnt(x, 0) + v_add3 trees, so the chain is spelled out.
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+
 __device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[8], const uint32_t *__restrict__ r) {
-    uint32_t d = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) d += __popc(q[k] ^ r[k]);
+    // two 16-byte loads: with a wave-uniform address these become s_load_dwordx4/x8 and the XORs take SGPR operands
+    const uint4 a = reinterpret_cast<const uint4 *>(r)[0], b = reinterpret_cast<const uint4 *>(r)[1];
+    uint32_t d = bcnt_acc(q[0] ^ a.x, 0);
+    d = bcnt_acc(q[1] ^ a.y, d);
+    d = bcnt_acc(q[2] ^ a.z, d);
+    d = bcnt_acc(q[3] ^ a.w, d);
+    d = bcnt_acc(q[4] ^ b.x, d);
+    d = bcnt_acc(q[5] ^ b.y, d);
+    d = bcnt_acc(q[6] ^ b.z, d);
+    d = bcnt_acc(q[7] ^ b.w, d);
     return d;
 }
 
@@ -51,8 +66,20 @@ __global__ __launch_bounds__(256) void knn2_scan_kernel(const uint32_t *__restri
     const int n = min(chunkLen, nr - j0);
     const uint32_t *__restrict__ rp = r + (size_t)j0 * 8;
     uint32_t best = kKeyNone, second = kKeyNone;
-#pragma unroll 4
-    for (int j = 0; j < n; j++) {
+    // four references per trip (32 SGPRs of s_load in flight); the inline-asm popcount chain keeps hipcc from unrolling a
+    // runtime-trip-count loop by itself
+    const int n4 = n & ~3;
+    for (int j = 0; j < n4; j += 4) {
+        const uint32_t *__restrict__ p4 = rp + (size_t)j * 8;
+        const uint32_t d0 = hamming256(qv, p4), d1 = hamming256(qv, p4 + 8), d2 = hamming256(qv, p4 + 16), d3 = hamming256(qv, p4 + 24);
+        const uint32_t k0 = (d0 << kKeyShift) | (uint32_t)j, k1 = (d1 << kKeyShift) | (uint32_t)(j + 1),
+                       k2 = (d2 << kKeyShift) | (uint32_t)(j + 2), k3 = (d3 << kKeyShift) | (uint32_t)(j + 3);
+        second = med3u(best, k0, second); best = min(best, k0);
+        second = med3u(best, k1, second); best = min(best, k1);
+        second = med3u(best, k2, second); best = min(best, k2);
+        second = med3u(best, k3, second); best = min(best, k3);
+    }
+    for (int j = n4; j < n; j++) {
         const uint32_t d = hamming256(qv, rp + (size_t)j * 8);
         const uint32_t key = (d << kKeyShift) | (uint32_t)j;
         second = med3u(best, key, second);
@@ -61,29 +88,45 @@ __global__ __launch_bounds__(256) void knn2_scan_kernel(const uint32_t *__restri
     if (qi < nq) partial[(size_t)blockIdx.y * nqPad + qi] = make_uint2(best, second);
 }
 
-// fold the chunks in ascending order (= ascending reference index) into the final (best_dist, best_idx, second_dist)
+// fold the chunks in ascending order (= ascending reference index) into the final (best_dist, best_idx, second_dist).
+// 64 queries per workgroup; the chunk range is cut into 4 consecutive groups folded by 4 waves in parallel, then the four
+// group results are folded in order (the update rule is associative over ordered segments).
+__device__ __forceinline__ void knn2_fold(uint32_t &bd, int &bi, uint32_t &sd, uint32_t d1, int i1, uint32_t d2) {
+    // a later segment contributes the ordered pair (d1 <= d2): apply the reference's update rule to both in scan order
+    if (d1 < bd) {
+        sd = min(bd, d2);
+        bd = d1;
+        bi = i1;
+    } else {
+        sd = min(sd, d1);
+    }
+}
+
 __global__ __launch_bounds__(256) void knn2_merge_kernel(const uint2 *__restrict__ partial, int nChunks, int nqPad, int nq,
                                                          int chunkLen, int idxBase, int *__restrict__ bestDist,
                                                          int *__restrict__ bestIdx, int *__restrict__ secondDist) {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq) return;
+    __shared__ uint32_t sBd[4][64], sSd[4][64];
+    __shared__ int sBi[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 64 + lane;
+    const int per = (nChunks + 3) / 4;
+    const int cBeg = grp * per, cEnd = min(cBeg + per, nChunks);
     uint32_t bd = 256, sd = 256;
     int bi = -1;
-    for (int c = 0; c < nChunks; c++) {
-        const uint2 p = partial[(size_t)c * nqPad + qi];
-        const uint32_t d1 = p.x >> kKeyShift, d2 = p.y >> kKeyShift;
-        // the chunk contributes the ordered pair (d1 <= d2); apply the reference's update rule to both in scan order
-        if (d1 < bd) {
-            sd = min(bd, d2);
-            bd = d1;
-            bi = idxBase + c * chunkLen + (int)(p.x & kKeyIdxMask);
-        } else {
-            sd = min(sd, d1);
+    if (qi < nq)
+        for (int c = cBeg; c < cEnd; c++) {
+            const uint2 p = partial[(size_t)c * nqPad + qi];
+            knn2_fold(bd, bi, sd, p.x >> kKeyShift, idxBase + c * chunkLen + (int)(p.x & kKeyIdxMask), p.y >> kKeyShift);
         }
+    sBd[grp][lane] = bd; sSd[grp][lane] = sd; sBi[grp][lane] = bi;
+    __syncthreads();
+    if (grp == 0 && qi < nq) {
+#pragma unroll
+        for (int gidx = 1; gidx < 4; gidx++) knn2_fold(bd, bi, sd, sBd[gidx][lane], sBi[gidx][lane], sSd[gidx][lane]);
+        bestDist[qi] = (int)bd;
+        bestIdx[qi] = bi;
+        secondDist[qi] = (int)sd;
     }
-    bestDist[qi] = (int)bd;
-    bestIdx[qi] = bi;
-    secondDist[qi] = (int)sd;
 }
 
 // candidate-list argmin: one query per lane, candidates scanned in list order
