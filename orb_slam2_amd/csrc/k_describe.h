@@ -24,6 +24,7 @@ struct DescribeArgs {
     uint8_t *desc;           // [F][cap][32]
     int *counts;             // [F]
     int cap;
+    int nFrames, groupsPerFrame;
 };
 
 // umax[v] of the reference constructor (src/ORBextractor.cc:454-469) for HALF_PATCH_SIZE = 15; the host re-derives the
@@ -98,8 +99,14 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double *s, double *c) {
 
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     const int lane = threadIdx.x & 63;
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // keypoint index inside the frame, level-major
+    // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (private L2s), so block id % 8 selects
+    // the XCD.  All blocks of frame f get ids with id % 8 == f % 8: a frame's patches (about 3 MB of level + blurred
+    // bytes, gathered ~2.5 KB per keypoint) then stay in ONE 4-MiB L2 instead of being pulled into all eight.
+    const int bid = blockIdx.x;
+    const int f = 8 * ((bid >> 3) / a.groupsPerFrame) + (bid & 7);
+    const int grp = (bid >> 3) % a.groupsPerFrame;
+    if (f >= a.nFrames) return;
+    const int i = grp * 4 + (threadIdx.x >> 6);   // keypoint index inside the frame, level-major
     // level prefix (<= 16 entries, wave-uniform)
     int lvl = -1, j = i, total = 0;
     for (int l = 0; l < a.g.nlevels; l++) {

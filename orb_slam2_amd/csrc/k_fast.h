@@ -152,109 +152,117 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     const u16x2 thPair = as_pk((uint32_t)a.minTh | ((uint32_t)a.minTh << 16));
 
     uint32_t A[7], B[7], C[7];
+    // prologue: rows Y0-3 .. Y0+2 into window slots 0..5 (16 <= row <= h-17: always inside the image)
 #pragma unroll
-    for (int u = 0; u < 7; u++) A[u] = B[u] = C[u] = 0;
+    for (int u = 0; u < 6; u++) {
+        B[u] = *reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 - 3 + u) * pitch + xl);
+        A[u] = dpp_from_left(B[u]);
+        C[u] = dpp_from_right(B[u]);
+    }
+    A[6] = B[6] = C[6] = 0;
     FastRowS cur, prev;                 // score rows c (newest) and c-1
     u16x2 ppMe = as_pk(0u), ppMo = as_pk(0u);   // row c-2, vertical contribution only
     prev.se = prev.so = prev.he = prev.ho = prev.me = prev.mo = as_pk(0u);
     cur = prev;
+    const u16x2 one = as_pk(0x00010001u);
 
-    const int steps = dh + 7;
-    for (int tb = 0; tb < steps; tb += 7) {
+    // append the kept scores of one output row (bytes of Pd) to the wave's survivor list, row-major
+    auto emit_row = [&](uint32_t Pd, int o) {
+        if (__ballot(Pd != 0) != 0) {   // wave-uniform: about one row step in ten has no survivor at all
+            const unsigned long long B0 = __ballot((Pd & 0xFFu) != 0), B1 = __ballot((Pd & 0xFF00u) != 0),
+                                     B2 = __ballot((Pd & 0xFF0000u) != 0), B3 = __ballot((Pd & 0xFF000000u) != 0);
+            // lanes ascending, then the lane's bytes ascending
+            int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
+                      __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0)) +
+                      __builtin_amdgcn_mbcnt_hi((uint32_t)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B2, 0)) +
+                      __builtin_amdgcn_mbcnt_hi((uint32_t)(B3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B3, 0));
 #pragma unroll
-        for (int u = 0; u < 7; u++) {
-            const int tt = tb + u;
-            if (tt >= steps) break;
-            if (tt < dh + 6) {
-                const int py = Y0 - 3 + tt;       // 16 <= py <= h-17: always inside the image
-                B[u] = *reinterpret_cast<const uint32_t *>(img + (size_t)py * pitch + xl);
-                A[u] = dpp_from_left(B[u]);
-                C[u] = dpp_from_right(B[u]);
-            }
-            if (tt >= 6 && tt < dh + 6) {
-                // ---- scores of row c = Y0 + tt - 6; window slots: row c-3 = (u+1)%7 ... row c = (u+4)%7 ... row c+3 = u
-                const int s0 = (u + 1) % 7, s1 = (u + 2) % 7, s2 = (u + 3) % 7, s3 = (u + 4) % 7, s4 = (u + 5) % 7,
-                          s5 = (u + 6) % 7, s6 = u;
-                uint32_t W[16];
-                // ring offsets (dx,dy), k = 0..15: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),
-                //                                  (-3,-1),(-3,0),(-3,1),(-2,2),(-1,3)
-                W[0] = B[s6];
-                W[1] = __builtin_amdgcn_alignbyte(C[s6], B[s6], 1);
-                W[2] = __builtin_amdgcn_alignbyte(C[s5], B[s5], 2);
-                W[3] = __builtin_amdgcn_alignbyte(C[s4], B[s4], 3);
-                W[4] = __builtin_amdgcn_alignbyte(C[s3], B[s3], 3);
-                W[5] = __builtin_amdgcn_alignbyte(C[s2], B[s2], 3);
-                W[6] = __builtin_amdgcn_alignbyte(C[s1], B[s1], 2);
-                W[7] = __builtin_amdgcn_alignbyte(C[s0], B[s0], 1);
-                W[8] = B[s0];
-                W[9] = __builtin_amdgcn_alignbyte(B[s0], A[s0], 3);
-                W[10] = __builtin_amdgcn_alignbyte(B[s1], A[s1], 2);
-                W[11] = __builtin_amdgcn_alignbyte(B[s2], A[s2], 1);
-                W[12] = __builtin_amdgcn_alignbyte(B[s3], A[s3], 1);
-                W[13] = __builtin_amdgcn_alignbyte(B[s4], A[s4], 1);
-                W[14] = __builtin_amdgcn_alignbyte(B[s5], A[s5], 2);
-                W[15] = __builtin_amdgcn_alignbyte(B[s6], A[s6], 3);
-                u16x2 r[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) r[k] = pair_even(W[k]);
-                const u16x2 se = fast_arc_score_pk(pair_even(B[s3]), r);
-#pragma unroll
-                for (int k = 0; k < 16; k++) r[k] = pair_odd(W[k]);
-                const u16x2 so = fast_arc_score_pk(pair_odd(B[s3]), r);
-                // shift the score-row window
-                ppMe = prev.me; ppMo = prev.mo;
-                prev = cur;
-                cur.se = se; cur.so = so;
-                // horizontal neighbours: even pixels (0,2) see (-1,1) and (1,3); odd pixels (1,3) see (0,2) and (2,4)
-                const uint32_t soL = dpp_from_left(as_u32(so)), seR = dpp_from_right(as_u32(se));
-                const u16x2 le = as_pk(__builtin_amdgcn_alignbit(as_u32(so), soL, 16) & mLe);
-                const u16x2 re = as_pk(as_u32(so) & mRe);
-                const u16x2 lo = as_pk(as_u32(se) & mLo);
-                const u16x2 ro = as_pk(__builtin_amdgcn_alignbit(seR, as_u32(se), 16) & mRo);
-                cur.he = pkmax(le, re);
-                cur.ho = pkmax(lo, ro);
-                cur.me = pkmax(cur.he, se);
-                cur.mo = pkmax(cur.ho, so);
-            }
-            if (tt >= 7) {
-                // ---- output row o = Y0 + tt - 7.  While scores are still being produced (tt < dh+6) row o is `prev`
-                //      (rows o-1 = pp, o+1 = cur); on the last step no new row was shifted in, so row o is `cur`.
-                const int o = tt - 7;
-                const bool last = tt == dh + 6;
-                const FastRowS &R = last ? cur : prev;
-                const u16x2 upE = last ? prev.me : ppMe, upO = last ? prev.mo : ppMo;
-                const uint32_t topOK = o > 0 ? 0xFFFFFFFFu : 0u, botOK = last ? 0u : 0xFFFFFFFFu;
-                u16x2 ne = pkmax(R.he, as_pk(as_u32(upE) & topOK)), no = pkmax(R.ho, as_pk(as_u32(upO) & topOK));
-                ne = pkmax(ne, as_pk(as_u32(cur.me) & botOK));
-                no = pkmax(no, as_pk(as_u32(cur.mo) & botOK));
-                // keep S iff S > max(neighbours, minTh)
-                const u16x2 one = as_pk(0x00010001u);
-                const u16x2 ke = pkmin(pksubsat(R.se, pkmax(ne, thPair)), one), ko = pkmin(pksubsat(R.so, pkmax(no, thPair)), one);
-                const uint32_t pe = as_u32(R.se * ke), po = as_u32(R.so * ko);
-                const uint32_t Pd = (pe | (po << 8)) & ownMask;   // bytes = kept scores of the lane's four pixels
-                if (__ballot(Pd != 0) != 0) {   // wave-uniform: about one row step in ten has no survivor at all
-                    const unsigned long long B0 = __ballot((Pd & 0xFFu) != 0), B1 = __ballot((Pd & 0xFF00u) != 0),
-                                             B2 = __ballot((Pd & 0xFF0000u) != 0), B3 = __ballot((Pd & 0xFF000000u) != 0);
-                    // row-major order: lanes ascending, then the lane's bytes ascending
-                    int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
-                              __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0)) +
-                              __builtin_amdgcn_mbcnt_hi((uint32_t)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B2, 0)) +
-                              __builtin_amdgcn_mbcnt_hi((uint32_t)(B3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B3, 0));
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const uint32_t sv = (Pd >> (8 * b)) & 0xFFu;
-                        if (sv) {
-                            if (pos < kFastListCap) {
-                                sList[wvi][pos] = sv | recBase[b] | ((uint32_t)o << 17);
-                                atomicMax(&sCellMax[wvi][(recBase[b] >> 8) & 7], (int)sv);
-                            }
-                            pos++;
-                        }
+            for (int b = 0; b < 4; b++) {
+                const uint32_t sv = (Pd >> (8 * b)) & 0xFFu;
+                if (sv) {
+                    if (pos < kFastListCap) {
+                        sList[wvi][pos] = sv | recBase[b] | ((uint32_t)o << 17);
+                        atomicMax(&sCellMax[wvi][(recBase[b] >> 8) & 7], (int)sv);
                     }
-                    listCount += __popcll(B0) + __popcll(B1) + __popcll(B2) + __popcll(B3);
+                    pos++;
                 }
             }
+            listCount += __popcll(B0) + __popcll(B1) + __popcll(B2) + __popcll(B3);
         }
+    };
+
+    // steady state, one detection row c per step: load row Y0+3+c into slot (6+c)%7, score row c, emit row c-1
+    for (int cb = 0; cb < dh; cb += 7) {
+#pragma unroll
+        for (int u7 = 0; u7 < 7; u7++) {
+            const int c = cb + u7;
+            if (c >= dh) break;
+            const int u = (6 + u7) % 7;   // slot of the newest row
+            B[u] = *reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 + 3 + c) * pitch + xl);
+            A[u] = dpp_from_left(B[u]);
+            C[u] = dpp_from_right(B[u]);
+            // window slots: row c-3 = (u+1)%7 ... row c = (u+4)%7 ... row c+3 = u
+            const int s0 = (u + 1) % 7, s1 = (u + 2) % 7, s2 = (u + 3) % 7, s3 = (u + 4) % 7, s4 = (u + 5) % 7,
+                      s5 = (u + 6) % 7, s6 = u;
+            uint32_t W[16];
+            // ring offsets (dx,dy), k = 0..15: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),
+            //                                  (-3,-1),(-3,0),(-3,1),(-2,2),(-1,3)
+            W[0] = B[s6];
+            W[1] = __builtin_amdgcn_alignbyte(C[s6], B[s6], 1);
+            W[2] = __builtin_amdgcn_alignbyte(C[s5], B[s5], 2);
+            W[3] = __builtin_amdgcn_alignbyte(C[s4], B[s4], 3);
+            W[4] = __builtin_amdgcn_alignbyte(C[s3], B[s3], 3);
+            W[5] = __builtin_amdgcn_alignbyte(C[s2], B[s2], 3);
+            W[6] = __builtin_amdgcn_alignbyte(C[s1], B[s1], 2);
+            W[7] = __builtin_amdgcn_alignbyte(C[s0], B[s0], 1);
+            W[8] = B[s0];
+            W[9] = __builtin_amdgcn_alignbyte(B[s0], A[s0], 3);
+            W[10] = __builtin_amdgcn_alignbyte(B[s1], A[s1], 2);
+            W[11] = __builtin_amdgcn_alignbyte(B[s2], A[s2], 1);
+            W[12] = __builtin_amdgcn_alignbyte(B[s3], A[s3], 1);
+            W[13] = __builtin_amdgcn_alignbyte(B[s4], A[s4], 1);
+            W[14] = __builtin_amdgcn_alignbyte(B[s5], A[s5], 2);
+            W[15] = __builtin_amdgcn_alignbyte(B[s6], A[s6], 3);
+            u16x2 r[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) r[k] = pair_even(W[k]);
+            const u16x2 se = fast_arc_score_pk(pair_even(B[s3]), r);
+#pragma unroll
+            for (int k = 0; k < 16; k++) r[k] = pair_odd(W[k]);
+            const u16x2 so = fast_arc_score_pk(pair_odd(B[s3]), r);
+            // shift the score-row window
+            ppMe = prev.me; ppMo = prev.mo;
+            prev = cur;
+            cur.se = se; cur.so = so;
+            // horizontal neighbours: even pixels (0,2) see (-1,1) and (1,3); odd pixels (1,3) see (0,2) and (2,4)
+            const uint32_t soL = dpp_from_left(as_u32(so)), seR = dpp_from_right(as_u32(se));
+            const u16x2 le = as_pk(__builtin_amdgcn_alignbit(as_u32(so), soL, 16) & mLe);
+            const u16x2 re = as_pk(as_u32(so) & mRe);
+            const u16x2 lo = as_pk(as_u32(se) & mLo);
+            const u16x2 ro = as_pk(__builtin_amdgcn_alignbit(seR, as_u32(se), 16) & mRo);
+            cur.he = pkmax(le, re);
+            cur.ho = pkmax(lo, ro);
+            cur.me = pkmax(cur.he, se);
+            cur.mo = pkmax(cur.ho, so);
+            // ---- output row o = c-1 (`prev`): rows o-1 = pp (masked on the cell's first row), o+1 = cur.
+            //      For c = 0 there is no row yet: prev is all zero, so nothing is kept.
+            const uint32_t topOK = c > 1 ? 0xFFFFFFFFu : 0u;
+            u16x2 ne = pkmax(prev.he, as_pk(as_u32(ppMe) & topOK)), no = pkmax(prev.ho, as_pk(as_u32(ppMo) & topOK));
+            ne = pkmax(ne, cur.me);
+            no = pkmax(no, cur.mo);
+            // keep S iff S > max(neighbours, minTh)
+            const u16x2 ke = pkmin(pksubsat(prev.se, pkmax(ne, thPair)), one), ko = pkmin(pksubsat(prev.so, pkmax(no, thPair)), one);
+            const uint32_t pe = as_u32(prev.se * ke), po = as_u32(prev.so * ko);
+            emit_row((pe | (po << 8)) & ownMask, c - 1);
+        }
+    }
+    {
+        // ---- last row o = dh-1 (`cur`): row above = prev (masked if the cell row has a single row), nothing below
+        const uint32_t topOK = dh > 1 ? 0xFFFFFFFFu : 0u;
+        const u16x2 ne = pkmax(cur.he, as_pk(as_u32(prev.me) & topOK)), no = pkmax(cur.ho, as_pk(as_u32(prev.mo) & topOK));
+        const u16x2 ke = pkmin(pksubsat(cur.se, pkmax(ne, thPair)), one), ko = pkmin(pksubsat(cur.so, pkmax(no, thPair)), one);
+        const uint32_t pe = as_u32(cur.se * ke), po = as_u32(cur.so * ko);
+        emit_row((pe | (po << 8)) & ownMask, dh - 1);
     }
 
     // ---- flush: per-cell threshold, one reservation in the level's dense array, candidates grouped by cell

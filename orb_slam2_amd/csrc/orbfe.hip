@@ -577,7 +577,9 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.counts = dCounts;
         a.cap = cap;
         const int maxKp = std::min(g.selFrameCap, cap);
-        hipLaunchKernelGGL(orient_describe_kernel, dim3((maxKp + 3) / 4, F), dim3(256), 0, st, a);
+        a.nFrames = F;
+        a.groupsPerFrame = (maxKp + 3) / 4;
+        hipLaunchKernelGGL(orient_describe_kernel, dim3((unsigned)a.groupsPerFrame * ((F + 7) / 8 * 8)), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     if (prof) {
