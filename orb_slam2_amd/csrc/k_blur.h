@@ -13,7 +13,7 @@
 //     v_alignbyte_b32 (weights 18,34,49,55 | 49,34,18,0);
 //   * column pass: the last seven row results stay in registers (the loop is unrolled by 7 so the window rotates by
 //     renaming); the symmetric kernel needs 3 adds + 4 multiply-adds per pixel; one dword store per lane and row.
-// Reflection only costs on the image's own edges (edge lanes assemble their dword from reflected bytes).
+// Reflection is branch-free: the image's edge lanes patch their dwords with byte permutes (v_perm_b32).
 // One launch covers every level of every frame: blockIdx.x walks a host-built (level, strip, row-block) list, 4 entries
 // per 256-thread workgroup, blockIdx.y is the frame.
 #pragma once
@@ -32,17 +32,11 @@ __device__ __forceinline__ int refl101(int p, int n) {
     return p >= n ? 2 * (n - 1) - p : p;
 }
 
-__device__ __forceinline__ uint32_t blur_load_dword(const uint8_t *row, int x0, int w) {
-    if (x0 >= 0 && x0 + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x0);
-    uint32_t v = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        int xx = x0 + b;
-        // columns further than 3 px outside the image never reach a valid output; the clamp only keeps the read legal
-        xx = xx < -3 ? 0 : (xx > w + 2 ? w - 1 : refl101(xx, w));
-        v |= (uint32_t)row[xx] << (8 * b);
-    }
-    return v;
+__device__ __forceinline__ uint32_t dpp_lane_m1(uint32_t v) {   // lane i <- lane i-1 (wave_shr:1), 0 into lane 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_lane_p1(uint32_t v) {   // lane i <- lane i+1 (wave_shl:1), 0 into lane 63
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
 }
 
 __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const BlurTile *tiles, int nTiles) {
@@ -60,6 +54,24 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
     const int y0 = t.ty * kBlurRows;
     const bool writer = lane >= 1 && lane <= kBlurStripDw && x0 < w;
 
+    // Horizontal BORDER_REFLECT_101 without byte loads or branches.  Every lane loads an aligned dword from a clamped,
+    // always legal address; the two places where reflected pixels are needed are patched with byte permutes:
+    //   left edge  (lane with x0 == 0): its left neighbour dword holds pixels (4,3,2,1) -> a permute of its own dword;
+    //   right edge (lane holding the last pixel xe = w-1, byte r = xe & 3): bytes r+1..3 of its dword and the first
+    //              bytes of its right neighbour are pixels xe-1, xe-2, ... taken from {own dword, left neighbour dword}.
+    const int xe = w - 1, r = xe & 3;
+    const bool isLeftEdge = x0 == 0, isRightEdge = x0 == (xe & ~3);
+    uint32_t selC = 0, selR = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int tc = b <= r ? b : 2 * r - b;             // source offset relative to the edge dword, -3..3
+        const int tr = max(2 * r - 4 - b, -4);             // right neighbour: pixel xe - (4 + b - r); only b < r is used
+        selC |= (uint32_t)(tc + 4) << (8 * b);
+        selR |= (uint32_t)(tr + 4) << (8 * b);
+    }
+    const uint32_t selL = 0x01020300u;
+    const uint32_t xl = (uint32_t)min(max(x0, 0), pitch - 4);
+
     constexpr uint32_t W1 = 18u | (34u << 8) | (49u << 16) | (55u << 24);
     constexpr uint32_t W2 = 49u | (34u << 8) | (18u << 16);
     uint32_t R[7][4];
@@ -74,10 +86,13 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
         for (int u = 0; u < 7; u++) {
             const int tt = tb + u;
             const int yy = refl101(min(y0 - 3 + tt, h + 2), h);
-            const uint32_t C = blur_load_dword(img + (size_t)yy * pitch, x0, w);
-            // neighbours: lane-1 / lane+1 (wave_shr:1 / wave_shl:1); the wave's edge lanes are halo and never write
-            const uint32_t Lf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xf, 0xf, false);
-            const uint32_t Rt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xf, 0xf, false);
+            const uint8_t *rowp = img + (size_t)yy * pitch;     // wave-uniform base, 32-bit per-lane offset
+            const uint32_t Craw = *reinterpret_cast<const uint32_t *>(rowp + xl);
+            const uint32_t Lraw = dpp_lane_m1(Craw);
+            const uint32_t C = isRightEdge ? __builtin_amdgcn_perm(Craw, Lraw, selC) : Craw;
+            const uint32_t Lf = isLeftEdge ? __builtin_amdgcn_perm(C, C, selL) : Lraw;   // lanes left of the right edge are unpatched
+            const uint32_t Rnb = dpp_lane_p1(C);
+            const uint32_t Rt = isRightEdge ? __builtin_amdgcn_perm(Craw, Lraw, selR) : Rnb;
             // row pass for the dword's four pixels: bytes x-3..x+3 of pixel x
             const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lf, 1), a1 = __builtin_amdgcn_alignbyte(C, Lf, 2),
                            a2 = __builtin_amdgcn_alignbyte(C, Lf, 3);
@@ -88,18 +103,18 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
             R[u][2] = __builtin_amdgcn_udot4(b2, W2, __builtin_amdgcn_udot4(a2, W1, 0u, false), false);
             R[u][3] = __builtin_amdgcn_udot4(Rt, W2, __builtin_amdgcn_udot4(C, W1, 0u, false), false);
             const int y = y0 + tt - 6;   // the row whose seven row results are now complete
-            if (tt >= 6 && y < h && writer) {
+            if (tt >= 6 && y < h) {      // wave-uniform
                 uint32_t out = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // window, oldest to newest: R[(u+1)%7] ... R[u]
-                    // row results are <= 255*257 = 65535, pair sums < 2^17: 24-bit multiplies (full rate) are exact
+                    // row results are <= 255*257 = 65535, pair sums < 2^17: 24-bit multiplies are exact
                     const uint32_t acc = __umul24(18u, R[(u + 1) % 7][k] + R[u][k]) + __umul24(34u, R[(u + 2) % 7][k] + R[(u + 6) % 7][k]) +
                                          __umul24(49u, R[(u + 3) % 7][k] + R[(u + 5) % 7][k]) + __umul24(55u, R[(u + 4) % 7][k]);
                     const uint32_t d = min((acc + 32768u) >> 16, 255u);
                     out |= d << (8 * k);
                 }
-                *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.pitch + x0) = out;   // pitch >= round_up(w,4)
+                if (writer) *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.pitch + x0) = out;   // pitch >= round_up(w,4)
             }
         }
     }
