@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per step and rank")
+    ap.add_argument("--handles", type=int, default=1,
+                    help="extractor handles (one HIP stream each) the step's frames are split over; the reference itself "
+                         "runs two extractor objects concurrently (src/Frame.cc:78-81)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     args = ap.parse_args()
@@ -97,26 +100,50 @@ def main():
     kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     cnt = torch.zeros(B, dtype=torch.int32, device=dev)
-    ex = capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+    # The step's B frames are split over `handles` extractor objects.  Each owns a HIP stream, so the latency-bound
+    # stages of one half (pyramid chain, quadtree) run under the VALU-bound stages of the other (FAST, blur, describe).
+    nh = max(1, min(args.handles, B))
+    bounds = [B * k // nh for k in range(nh + 1)]
+    exs = [capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank) for _ in range(nh)]
 
     def step():
-        # asynchronous on the library's stream: the K steps queue back to back, as an offline extraction job would
-        ex.extract_batch_device(frames.data_ptr(), B, W, H, stride, stride * H, kps.data_ptr(), desc.data_ptr(),
-                                cnt.data_ptr(), cap, sync=False)
+        # asynchronous on the library's streams: the K steps queue back to back, as an offline extraction job would
+        for k, ex in enumerate(exs):
+            f0, f1 = bounds[k], bounds[k + 1]
+            ex.extract_batch_device(frames[f0].data_ptr(), f1 - f0, W, H, stride, stride * H, kps[f0].data_ptr(),
+                                    desc[f0].data_ptr(), cnt[f0:].data_ptr(), cap, sync=False)
+
+    def sync_all():
+        for ex in exs:
+            ex.synchronize()    # the library's own streams (torch.cuda.synchronize does not cover non-blocking streams)
 
     for _ in range(args.warmup):
         step()
-    ex.synchronize()
-    ex.set_profiling(True)      # HIP events on the library's stream around every stage; never blocks the stream
+    sync_all()
+    for ex in exs:
+        ex.set_profiling(2)     # two HIP events per step on the library's stream, around the FAST kernel; never blocks
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ex.synchronize()            # the library's own stream (torch.cuda.synchronize does not cover a non-blocking stream)
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
-    prof = ex.profile()
-    ex.set_profiling(False)
+    profs = [ex.profile() for ex in exs]
+    # stage table: a short un-timed pass with events around every stage
+    for ex in exs:
+        ex.set_profiling(1)
+    for _ in range(5):
+        step()
+    sync_all()
+    stage_profs = [ex.profile() for ex in exs]
+    for ex in exs:
+        ex.set_profiling(0)
+    stages = {k: round(sum(p["stage_ms"][k] for p in stage_profs) / 5, 4) for k in stage_profs[0]["stage_ms"]}
+    prof = {"stage_ms": {k: sum(p["stage_ms"][k] for p in profs) for k in profs[0]["stage_ms"]},
+            "stage_launches": {k: sum(p["stage_launches"][k] for p in profs) for k in profs[0]["stage_launches"]},
+            "frames": sum(p["frames"] for p in profs), "candidates": sum(p["candidates"] for p in profs),
+            "keypoints": sum(p["keypoints"] for p in profs)}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -128,12 +155,21 @@ def main():
     # ---- roofline of the dominant kernel (FAST): algorithmic bytes = level pixels read + 8 B per candidate written
     fast_ms = prof["stage_ms"]["fast"] / max(prof["stage_launches"]["fast"], 1)
     cand_per_frame = prof["candidates"] / max(prof["frames"], 1)
-    fast_bytes = B * (LEVEL_PIXELS + 8 * cand_per_frame)
+    frames_per_launch = prof["frames"] / max(prof["stage_launches"]["fast"], 1)
+    fast_bytes = frames_per_launch * (LEVEL_PIXELS + 8 * cand_per_frame)
     achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
-    stages = {k: round(v / max(args.steps, 1), 4) for k, v in prof["stage_ms"].items()}
+    # traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at 64 frames per launch
+    # (profiles/r1_pmc_fetch_write_summary.txt): 2 x 57.1 MB fetched (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md) +
+    # 6.8 MB written = 1.89 MB per frame; scaled to the frames one launch of this run processes.
+    traffic = int(frames_per_launch * (2 * 57105.3 + 6755.7) * 1024 / 64)
     roofline = {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "ms_per_launch": round(fast_ms, 4), "algorithmic_bytes_per_launch": int(fast_bytes),
+                "frames_per_launch": frames_per_launch,
+                "note": "FAST is integer-VALU-bound (~250 packed min/max per 4 pixels at the measured 38 T lane-ops/s), not "
+                        "HBM-bound; ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
+                        "--handles > 1 the other handle's kernels run concurrently and inflate it); stage_ms_per_step "
+                        "comes from 5 extra un-timed steps with events around every stage",
                 "stage_ms_per_step": stages}
 
     # ---- Hamming kNN-2: 2000 queries vs a 1M database sharded over the ranks, RCCL gather of per-shard results
@@ -193,7 +229,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "batched ORB extraction, 1241x376 KITTI-size frames resident in HBM, 2000 features, "
                                    "8 levels, scale 1.2, FAST 20/7 (BASELINE.json configs[0] shape, configs[3] batching)",
-                       "frames_per_step_per_gpu": B, "keypoints_per_frame": round(kp_per_frame, 1),
+                       "frames_per_step_per_gpu": B, "handles": nh, "keypoints_per_frame": round(kp_per_frame, 1),
                        "parallelism": f"frames sharded over {world} gpu(s), no collective"},
             "roofline": roofline, "cpu_baseline": cpu, "hamming": hamming,
         }

@@ -110,7 +110,9 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
 /* Per-stage device timing of the extractor, taken with HIP events recorded on the handle's stream around each
  * stage's kernel launches inside orbfe_extract / orbfe_extract_batch (no counterpart in the reference, whose only
  * timing is the wall clock around TrackStereo in Examples/Stereo/stereo_kitti.cc:80-97).  Enabling resets the sums.
- * Recording never blocks the stream; orbfe_get_profile drains the stream and folds the recorded events into the sums. */
+ * Recording never blocks the stream; orbfe_get_profile drains the stream and folds the recorded events into the sums.
+ * enable: 0 = off, 1 = every stage (six events per call), 2 = the FAST kernel only (two events per call, for timing a
+ * production-rate run with the least disturbance). */
 enum { ORBFE_STAGE_PYRAMID = 0, ORBFE_STAGE_FAST = 1, ORBFE_STAGE_BLUR = 2, ORBFE_STAGE_DESCRIBE = 3,
        ORBFE_STAGE_QUADTREE = 4, ORBFE_STAGE_COUNT = 5 };
 typedef struct orbfe_profile {

@@ -191,8 +191,9 @@ class ORBextractor:
         """'device' (default) or 'host' -- where DistributeOctTree runs; identical results."""
         check(self._L.orbfe_set_quadtree_mode(self._h, {"device": 0, "host": 1}[mode]))
 
-    def set_profiling(self, enable: bool):
-        check(self._L.orbfe_set_profiling(self._h, 1 if enable else 0))
+    def set_profiling(self, enable):
+        """False/0 off, True/1 every stage, 2 the FAST kernel only (least disturbance)."""
+        check(self._L.orbfe_set_profiling(self._h, int(enable)))
 
     def profile(self) -> dict:
         p = OrbfeProfile()

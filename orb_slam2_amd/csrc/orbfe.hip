@@ -123,13 +123,13 @@ struct orbfe_extractor {
     DevBuf dStatus;
     PinBuf hStatus;
     // optional per-stage timing with HIP events on the handle's stream (orbfe_set_profiling)
-    bool profiling = false;
+    int profiling = 0;   // 0 off, 1 every stage, 2 FAST kernel only (two events per call)
     // profiling never blocks the stream: each call records one ProfSet; sets are folded into the sums when the profile is
     // read (orbfe_get_profile), when profiling is switched, or when kMaxPendingProf sets are outstanding
     struct ProfSet {
         hipEvent_t ev[6] = {};
         int *counts = nullptr;   // pinned: [2][F][kMaxLevels] (level counts, kept counts)
-        int F = 0, capF = 0, nlevels = 0;
+        int F = 0, capF = 0, nlevels = 0, mode = 1;
         bool hostTree = false;
     };
     std::vector<ProfSet> profPool;
@@ -415,7 +415,7 @@ int host_quadtree_stage(orbfe_extractor *e, int F) {
         for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
         for (auto &th : pool) th.join();
     }
-    if (e->profiling)
+    if (e->profiling == 1)
         e->stageMs[ORBFE_STAGE_QUADTREE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIPCHK(hipMemcpyAsync(e->dSel.p, e->hSel.p, (size_t)F * g.selFrameCap * sizeof(SelKp), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e->dSelCount.p, e->hSelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyHostToDevice, st));
@@ -431,16 +431,18 @@ int prof_resolve(orbfe_extractor *e) {
     for (size_t i = 0; i < e->profPending; i++) {
         orbfe_extractor::ProfSet &p = e->profPool[i];
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, p.ev[0], p.ev[1])); e->stageMs[ORBFE_STAGE_PYRAMID] += ms;
         HIPCHK(hipEventElapsedTime(&ms, p.ev[1], p.ev[2])); e->stageMs[ORBFE_STAGE_FAST] += ms;
-        HIPCHK(hipEventElapsedTime(&ms, p.ev[2], p.ev[3])); e->stageMs[ORBFE_STAGE_BLUR] += ms;
-        if (!p.hostTree) { HIPCHK(hipEventElapsedTime(&ms, p.ev[3], p.ev[4])); e->stageMs[ORBFE_STAGE_QUADTREE] += ms; }
-        HIPCHK(hipEventElapsedTime(&ms, p.ev[4], p.ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
-        e->stageLaunches[ORBFE_STAGE_PYRAMID] += p.nlevels - 1;
         e->stageLaunches[ORBFE_STAGE_FAST] += 1;
-        e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
-        e->stageLaunches[ORBFE_STAGE_QUADTREE] += 1;
-        e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
+        if (p.mode == 1) {
+            HIPCHK(hipEventElapsedTime(&ms, p.ev[0], p.ev[1])); e->stageMs[ORBFE_STAGE_PYRAMID] += ms;
+            HIPCHK(hipEventElapsedTime(&ms, p.ev[2], p.ev[3])); e->stageMs[ORBFE_STAGE_BLUR] += ms;
+            if (!p.hostTree) { HIPCHK(hipEventElapsedTime(&ms, p.ev[3], p.ev[4])); e->stageMs[ORBFE_STAGE_QUADTREE] += ms; }
+            HIPCHK(hipEventElapsedTime(&ms, p.ev[4], p.ev[5])); e->stageMs[ORBFE_STAGE_DESCRIBE] += ms;
+            e->stageLaunches[ORBFE_STAGE_PYRAMID] += p.nlevels - 1;
+            e->stageLaunches[ORBFE_STAGE_BLUR] += 1;
+            e->stageLaunches[ORBFE_STAGE_QUADTREE] += 1;
+            e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
+        }
         e->stageFrames += p.F;
         const int *lc = p.counts, *sc = p.counts + (size_t)p.F * kMaxLevels;
         for (int f = 0; f < p.F; f++)
@@ -492,13 +494,14 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     e->lastFrames = F;
     e->overflow = false;
 
-    const bool prof = e->profiling;
+    const bool profAny = e->profiling != 0, prof = e->profiling == 1;
     orbfe_extractor::ProfSet *ps = nullptr;
-    if (prof) {
+    if (profAny) {
         rc = prof_acquire(e, F, &ps);
         if (rc) return rc;
         e->ev = ps->ev;
-        HIPCHK(hipEventRecord(e->ev[0], st));
+        ps->mode = e->profiling;
+        if (prof) HIPCHK(hipEventRecord(e->ev[0], st));
     }
     // K1: pyramid, level by level (level l reads level l-1)
     for (int l = 1; l < g.nlevels; l++) {
@@ -524,7 +527,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     HIPCHK(hipMemsetAsync(e->dLevelCount.p, 0, (size_t)F * kMaxLevels * sizeof(int), st));
     HIPCHK(hipMemsetAsync(e->dCellTab.p, 0, (size_t)F * g.totalCells * sizeof(int2), st));
     HIPCHK(hipMemsetAsync(e->dStatus.p, 0, sizeof(int), st));
-    if (prof) HIPCHK(hipEventRecord(e->ev[1], st));
+    if (profAny) HIPCHK(hipEventRecord(e->ev[1], st));
     {
         const int iniTh = std::min(std::max(e->p.ini_th_fast, 0), 255), minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
         FastArgs a;
@@ -541,7 +544,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         if (iniTh < minTh) a.iniTh = a.minTh = iniTh;
         hipLaunchKernelGGL(fast_cells_kernel, dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
     }
-    if (prof) HIPCHK(hipEventRecord(e->ev[2], st));
+    if (profAny) HIPCHK(hipEventRecord(e->ev[2], st));
     // K5: blur of every level
     hipLaunchKernelGGL(gauss7_kernel, dim3(((unsigned)e->hBlurTiles.size() + 3) / 4, F), dim3(256), 0, st, g, src,
                        (const BlurTile *)e->dBlurTiles.p, (int)e->hBlurTiles.size());
@@ -582,8 +585,8 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         hipLaunchKernelGGL(orient_describe_kernel, dim3((unsigned)a.groupsPerFrame * ((F + 7) / 8 * 8)), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
-    if (prof) {
-        HIPCHK(hipEventRecord(e->ev[5], st));
+    if (profAny) {
+        if (prof) HIPCHK(hipEventRecord(e->ev[5], st));
         ps->hostTree = hostTree;
         HIPCHK(hipMemcpyAsync(ps->counts, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ps->counts + (size_t)F * kMaxLevels, e->dSelCount.p, (size_t)F * kMaxLevels * sizeof(int),
@@ -640,7 +643,7 @@ int orbfe_set_profiling(orbfe_extractor *e, int enable) {
     HIPCHK(hipSetDevice(e->device));
     int rc = prof_resolve(e);
     if (rc) return rc;
-    e->profiling = enable != 0;
+    e->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     for (int i = 0; i < ORBFE_STAGE_COUNT; i++) { e->stageMs[i] = 0; e->stageLaunches[i] = 0; }
     e->stageFrames = 0;
     e->candTotal = e->kpTotal = 0;
