@@ -14,15 +14,19 @@
 //
 // One kernel, fast_cells_kernel, register-sliding like the blur: one wavefront owns (one cell row) x (a strip of whole
 // cells, <= 56 dword columns) of one level and walks down the rows.  Per row each lane loads ONE aligned dword (coalesced
-// 256-B segments) and keeps the last 7 rows; left/right neighbour dwords come by DPP wave shifts.  The 16 ring values of
-// the dword's four pixels are cut out as byte windows (v_alignbyte) and processed two pixels at a time in packed 16-bit
-// lanes: the sixteen 9-windows' maxima/minima come from prefix/suffix maxima of the two ring halves (28 + 16
-// v_pk_max_u16 instead of 64), then a 15-op tree.  The strict 3x3 local-maximum test runs in the same registers (cell
-// edges masked).  Survivors above minTh (about 1 % of the pixels) are appended, in row-major order, to a per-wave LDS
-// list together with a per-cell running maximum.  Because a wave owns whole cells, the threshold decision is wave-local:
-// at the end of the strip the wave filters its list per cell, reserves space in the level's dense candidate array with
-// ONE atomicAdd and writes the candidates grouped by cell in cv::FAST's order; the cell's (offset, count) goes to a cell
-// table so a consumer can walk cells in the reference's order.  No barriers, no score plane in HBM.
+// 256-B segments) and immediately converts it to PAIR FORM: two pixels per register in 16-bit lanes, for the eight
+// horizontal offsets -3..+4 the ring needs (2 masks/permutes, 4 DPP wave shifts for the neighbour lanes' pairs, 4
+// v_alignbit).  The last 7 rows stay in registers in that form, so the sixteen ring values of both pixel pairs of every
+// row are plain register reads.  Arc score per pair: windows k and k+1 share ring[k+1..k+8], so
+//     min(max W_k, max W_k+1) = max(M8[k+1], min(ring[k], ring[k+9]))
+// with the eight M8 (maxima of 8 consecutive ring values from odd starts) built by doubling: 47 v_pk_max/min_u16 per
+// side, 97 per pixel pair.  The strict 3x3 local-maximum test runs in the same registers (cell edges masked).
+// A lane whose dword holds a survivor above minTh (about 1 % of the pixels) appends ONE record (the dword of kept
+// scores, lane, row) to a per-wave LDS list; records are in row-major order.  Because a wave owns whole cells, the
+// threshold decision is wave-local: at the end of the strip the wave takes each cell's maximum, filters its list per
+// cell, reserves space in the level's dense candidate array with ONE atomicAdd and writes the candidates grouped by cell
+// in cv::FAST's order; the cell's (offset, count) goes to a cell table so a consumer can walk cells in the reference's
+// order.  No barriers, no score plane in HBM.
 #pragma once
 #include "common.h"
 
@@ -32,7 +36,7 @@ constexpr int kFastStripMaxDw = 60;   // writer lanes 2..61; lanes 0,1 and 62,63
 
 struct FastTile { uint16_t level, strip, cellRow, pad; };
 
-constexpr int kFastListCap = 2048;    // survivors a wave can hold for its strip (dense texture: ~150)
+constexpr int kFastListCap = 1024;    // survivor records (one per lane and row) a wave can hold for its strip (dense texture: ~150)
 
 struct FastArgs {
     Geom g;
@@ -60,29 +64,24 @@ __device__ __forceinline__ u16x2 pair_odd(uint32_t w) { return as_pk(__builtin_a
 
 // arc score of two pixels at once: v = centres, r[k] = ring values, all in 16-bit lanes holding 0..255
 __device__ __forceinline__ u16x2 fast_arc_score_pk(u16x2 v, const u16x2 (&r)[16]) {
-    u16x2 preMx[16], sufMx[16], preMn[16], sufMn[16];
+    u16x2 x2[8], n2[8], x4[8], n4[8];
 #pragma unroll
-    for (int b = 0; b < 16; b += 8) {
-        preMx[b] = r[b];
-        preMn[b] = r[b];
-        sufMx[b + 7] = r[b + 7];
-        sufMn[b + 7] = r[b + 7];
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            preMx[b + j] = pkmax(preMx[b + j - 1], r[b + j]);
-            preMn[b + j] = pkmin(preMn[b + j - 1], r[b + j]);
-            sufMx[b + 7 - j] = pkmax(sufMx[b + 8 - j], r[b + 7 - j]);
-            sufMn[b + 7 - j] = pkmin(sufMn[b + 8 - j], r[b + 7 - j]);
-        }
+    for (int i = 0; i < 8; i++) {      // ring[j], ring[j+1], j = 2i+1
+        x2[i] = pkmax(r[2 * i + 1], r[(2 * i + 2) & 15]);
+        n2[i] = pkmin(r[2 * i + 1], r[(2 * i + 2) & 15]);
     }
-    // window of 9 starting at k (k < 8): ring[k..7] u ring[8..8+k];  starting at 8+k: ring[8+k..15] u ring[0..k]
+#pragma unroll
+    for (int i = 0; i < 8; i++) {      // ring[j..j+3]
+        x4[i] = pkmax(x2[i], x2[(i + 1) & 7]);
+        n4[i] = pkmin(n2[i], n2[(i + 1) & 7]);
+    }
     u16x2 minOfMax = as_pk(0x00FF00FFu), maxOfMin = as_pk(0u);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        minOfMax = pkmin(minOfMax, pkmax(sufMx[k], preMx[8 + k]));
-        minOfMax = pkmin(minOfMax, pkmax(sufMx[8 + k], preMx[k]));
-        maxOfMin = pkmax(maxOfMin, pkmin(sufMn[k], preMn[8 + k]));
-        maxOfMin = pkmax(maxOfMin, pkmin(sufMn[8 + k], preMn[k]));
+    for (int i = 0; i < 8; i++) {      // windows k = 2i and k+1 share ring[k+1..k+8] = M8[j = k+1]
+        const int k = 2 * i;
+        const u16x2 x8 = pkmax(x4[i], x4[(i + 2) & 7]), n8 = pkmin(n4[i], n4[(i + 2) & 7]);
+        minOfMax = pkmin(minOfMax, pkmax(x8, pkmin(r[k], r[(k + 9) & 15])));
+        maxOfMin = pkmax(maxOfMin, pkmin(n8, pkmax(r[k], r[(k + 9) & 15])));
     }
     return pkmax(pksubsat(v, minOfMax), pksubsat(maxOfMin, v));   // max(S, 0)
 }
@@ -100,8 +99,24 @@ struct FastRowS {      // one row of scores in pair form, with what the 3x3 test
     u16x2 me, mo;      // max of left, centre, right in this row (what the rows above/below see)
 };
 
+// one image row in pair form: q[o + 3] = pixels (x0 + o, x0 + o + 2) of the lane's dword, o = -3..4
+__device__ __forceinline__ void fast_row_pairs(uint32_t raw, uint32_t (&q)[8]) {
+    const uint32_t E = raw & 0x00FF00FFu;                                   // (p0, p2)
+    const uint32_t O = __builtin_amdgcn_perm(0u, raw, 0x0c030c01u);         // (p1, p3)
+    const uint32_t EL = dpp_from_left(E), OL = dpp_from_left(O);            // (p-4, p-2), (p-3, p-1)
+    const uint32_t ER = dpp_from_right(E), OR = dpp_from_right(O);          // (p4, p6),  (p5, p7)
+    q[0] = OL;
+    q[1] = __builtin_amdgcn_alignbit(E, EL, 16);                            // (p-2, p0)
+    q[2] = __builtin_amdgcn_alignbit(O, OL, 16);                            // (p-1, p1)
+    q[3] = E;
+    q[4] = O;
+    q[5] = __builtin_amdgcn_alignbit(ER, E, 16);                            // (p2, p4)
+    q[6] = __builtin_amdgcn_alignbit(OR, O, 16);                            // (p3, p5)
+    q[7] = ER;
+}
+
 __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
-    __shared__ uint32_t sList[4][kFastListCap];
+    __shared__ uint2 sList[4][kFastListCap];
     __shared__ int sCellMax[4][8];
     const int lane = threadIdx.x & 63;
     const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -123,15 +138,11 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     const int d = (Xs >> 2) + lane - 2;
     const int x0 = 4 * d;
     const int xl = min(max(x0, 0), pitch - 4);   // halo lanes beyond the row: any legal address, value unused
-    // per byte: is the pixel owned by this strip, and its (cell in strip, x in cell) packed for the survivor record
-    uint32_t ownMask = 0, recBase[4];
+    uint32_t ownMask = 0;                        // per byte: is the pixel a detection pixel of this strip
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const int x = x0 + b;
-        const bool own = x >= Xs && x < Xe;
-        const int cis = own ? (x - Xs) / L.wCell : 0;
-        recBase[b] = ((uint32_t)cis << 8) | ((uint32_t)(own ? x - Xs - cis * L.wCell : 0) << 11);
-        ownMask |= own ? (0xFFu << (8 * b)) : 0u;
+        ownMask |= (x >= Xs && x < Xe) ? (0xFFu << (8 * b)) : 0u;
     }
     if (lane < 8) sCellMax[wvi][lane] = 0;
     int listCount = 0;   // wave-uniform
@@ -151,43 +162,26 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     }
     const u16x2 thPair = as_pk((uint32_t)a.minTh | ((uint32_t)a.minTh << 16));
 
-    uint32_t A[7], B[7], C[7];
+    uint32_t Q[7][8];
     // prologue: rows Y0-3 .. Y0+2 into window slots 0..5 (16 <= row <= h-17: always inside the image)
 #pragma unroll
-    for (int u = 0; u < 6; u++) {
-        B[u] = *reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 - 3 + u) * pitch + xl);
-        A[u] = dpp_from_left(B[u]);
-        C[u] = dpp_from_right(B[u]);
-    }
-    A[6] = B[6] = C[6] = 0;
+    for (int u = 0; u < 6; u++)
+        fast_row_pairs(*reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 - 3 + u) * pitch + xl), Q[u]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) Q[6][k] = 0;
     FastRowS cur, prev;                 // score rows c (newest) and c-1
     u16x2 ppMe = as_pk(0u), ppMo = as_pk(0u);   // row c-2, vertical contribution only
     prev.se = prev.so = prev.he = prev.ho = prev.me = prev.mo = as_pk(0u);
     cur = prev;
     const u16x2 one = as_pk(0x00010001u);
 
-    // append the kept scores of one output row (bytes of Pd) to the wave's survivor list, row-major
+    // a lane whose dword holds a kept score appends one record (kept scores, lane | row << 8); row-major order
     auto emit_row = [&](uint32_t Pd, int o) {
-        if (__ballot(Pd != 0) != 0) {   // wave-uniform: about one row step in ten has no survivor at all
-            const unsigned long long B0 = __ballot((Pd & 0xFFu) != 0), B1 = __ballot((Pd & 0xFF00u) != 0),
-                                     B2 = __ballot((Pd & 0xFF0000u) != 0), B3 = __ballot((Pd & 0xFF000000u) != 0);
-            // lanes ascending, then the lane's bytes ascending
-            int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
-                      __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0)) +
-                      __builtin_amdgcn_mbcnt_hi((uint32_t)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B2, 0)) +
-                      __builtin_amdgcn_mbcnt_hi((uint32_t)(B3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B3, 0));
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const uint32_t sv = (Pd >> (8 * b)) & 0xFFu;
-                if (sv) {
-                    if (pos < kFastListCap) {
-                        sList[wvi][pos] = sv | recBase[b] | ((uint32_t)o << 17);
-                        atomicMax(&sCellMax[wvi][(recBase[b] >> 8) & 7], (int)sv);
-                    }
-                    pos++;
-                }
-            }
-            listCount += __popcll(B0) + __popcll(B1) + __popcll(B2) + __popcll(B3);
+        const unsigned long long Bm = __ballot(Pd != 0);
+        if (Bm != 0) {   // wave-uniform
+            const int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, 0));
+            if (Pd != 0 && pos < kFastListCap) sList[wvi][pos] = make_uint2(Pd, (uint32_t)lane | ((uint32_t)o << 8));
+            listCount += __popcll(Bm);
         }
     };
 
@@ -198,38 +192,23 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
             const int c = cb + u7;
             if (c >= dh) break;
             const int u = (6 + u7) % 7;   // slot of the newest row
-            B[u] = *reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 + 3 + c) * pitch + xl);
-            A[u] = dpp_from_left(B[u]);
-            C[u] = dpp_from_right(B[u]);
+            fast_row_pairs(*reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 + 3 + c) * pitch + xl), Q[u]);
             // window slots: row c-3 = (u+1)%7 ... row c = (u+4)%7 ... row c+3 = u
             const int s0 = (u + 1) % 7, s1 = (u + 2) % 7, s2 = (u + 3) % 7, s3 = (u + 4) % 7, s4 = (u + 5) % 7,
                       s5 = (u + 6) % 7, s6 = u;
-            uint32_t W[16];
             // ring offsets (dx,dy), k = 0..15: (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),
-            //                                  (-3,-1),(-3,0),(-3,1),(-2,2),(-1,3)
-            W[0] = B[s6];
-            W[1] = __builtin_amdgcn_alignbyte(C[s6], B[s6], 1);
-            W[2] = __builtin_amdgcn_alignbyte(C[s5], B[s5], 2);
-            W[3] = __builtin_amdgcn_alignbyte(C[s4], B[s4], 3);
-            W[4] = __builtin_amdgcn_alignbyte(C[s3], B[s3], 3);
-            W[5] = __builtin_amdgcn_alignbyte(C[s2], B[s2], 3);
-            W[6] = __builtin_amdgcn_alignbyte(C[s1], B[s1], 2);
-            W[7] = __builtin_amdgcn_alignbyte(C[s0], B[s0], 1);
-            W[8] = B[s0];
-            W[9] = __builtin_amdgcn_alignbyte(B[s0], A[s0], 3);
-            W[10] = __builtin_amdgcn_alignbyte(B[s1], A[s1], 2);
-            W[11] = __builtin_amdgcn_alignbyte(B[s2], A[s2], 1);
-            W[12] = __builtin_amdgcn_alignbyte(B[s3], A[s3], 1);
-            W[13] = __builtin_amdgcn_alignbyte(B[s4], A[s4], 1);
-            W[14] = __builtin_amdgcn_alignbyte(B[s5], A[s5], 2);
-            W[15] = __builtin_amdgcn_alignbyte(B[s6], A[s6], 3);
+            //                                  (-3,-1),(-3,0),(-3,1),(-2,2),(-1,3);  even pair: q[dx+3], odd pair: q[dx+4]
             u16x2 r[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) r[k] = pair_even(W[k]);
-            const u16x2 se = fast_arc_score_pk(pair_even(B[s3]), r);
-#pragma unroll
-            for (int k = 0; k < 16; k++) r[k] = pair_odd(W[k]);
-            const u16x2 so = fast_arc_score_pk(pair_odd(B[s3]), r);
+#define ORBFE_RING(P)                                                                                                    \
+            r[0] = as_pk(Q[s6][3 + P]); r[1] = as_pk(Q[s6][4 + P]); r[2] = as_pk(Q[s5][5 + P]); r[3] = as_pk(Q[s4][6 + P]);     \
+            r[4] = as_pk(Q[s3][6 + P]); r[5] = as_pk(Q[s2][6 + P]); r[6] = as_pk(Q[s1][5 + P]); r[7] = as_pk(Q[s0][4 + P]);     \
+            r[8] = as_pk(Q[s0][3 + P]); r[9] = as_pk(Q[s0][2 + P]); r[10] = as_pk(Q[s1][1 + P]); r[11] = as_pk(Q[s2][0 + P]);   \
+            r[12] = as_pk(Q[s3][0 + P]); r[13] = as_pk(Q[s4][0 + P]); r[14] = as_pk(Q[s5][1 + P]); r[15] = as_pk(Q[s6][2 + P]);
+            ORBFE_RING(0)
+            const u16x2 se = fast_arc_score_pk(as_pk(Q[s3][3]), r);
+            ORBFE_RING(1)
+            const u16x2 so = fast_arc_score_pk(as_pk(Q[s3][4]), r);
+#undef ORBFE_RING
             // shift the score-row window
             ppMe = prev.me; ppMo = prev.mo;
             prev = cur;
@@ -265,7 +244,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
         emit_row((pe | (po << 8)) & ownMask, dh - 1);
     }
 
-    // ---- flush: per-cell threshold, one reservation in the level's dense array, candidates grouped by cell
+    // ---- flush: per-cell maximum -> threshold, one reservation in the level's dense array, candidates grouped by cell
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (listCount > kFastListCap) {
@@ -273,18 +252,50 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
         listCount = kFastListCap;
     }
     const int nCells = c1 - c0;                      // <= 8
+    const int wCell = L.wCell;
+    const int relLane0 = 4 * ((Xs >> 2) - 2) - Xs;   // x - Xs of byte 0 of lane 0
+    // pass A: cell maxima
+    for (int i0 = 0; i0 < listCount; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < listCount) {
+            const uint2 rec = sList[wvi][i];
+            const int rel0 = relLane0 + 4 * (int)(rec.y & 63);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int sv = (rec.x >> (8 * b)) & 0xFF;
+                if (sv) {
+                    const int rel = rel0 + b;
+                    int cis = 0;
+#pragma unroll
+                    for (int c = 1; c < 8; c++) cis += rel >= c * wCell ? 1 : 0;
+                    atomicMax(&sCellMax[wvi][cis], sv);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     int thCell[8], cntCell[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         thCell[c] = (c < nCells && sCellMax[wvi][c] > a.iniTh) ? a.iniTh : a.minTh;
         cntCell[c] = 0;
     }
+    // pass B: candidates per cell.  Two bytes of one dword can both be kept (never adjacent ones), possibly in two cells.
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
-        const uint32_t rec = i < listCount ? sList[wvi][i] : 0u;
-        const int cis = (rec >> 8) & 7, sv = rec & 0xFF;
+        const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
+        const int rel0 = relLane0 + 4 * (int)(rec.y & 63);
 #pragma unroll
-        for (int c = 0; c < 8; c++) cntCell[c] += __popcll(__ballot(i < listCount && cis == c && sv > thCell[c]));
+        for (int c = 0; c < 8; c++) {
+            int n = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int sv = (rec.x >> (8 * b)) & 0xFF, rel = rel0 + b;
+                n += (sv > thCell[c] && rel >= c * wCell && rel < (c + 1) * wCell) ? 1 : 0;
+            }
+            cntCell[c] += __popcll(__ballot(n >= 1)) + __popcll(__ballot(n >= 2));
+        }
     }
     int offCell[8], total = 0;
 #pragma unroll
@@ -302,26 +313,41 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     int run[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) run[c] = base + offCell[c];
+    // pass C: write, records ascending then bytes ascending inside each cell (= cv::FAST's row-major order)
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
-        const uint32_t rec = i < listCount ? sList[wvi][i] : 0u;
-        const int cis = (rec >> 8) & 7, sv = rec & 0xFF;
-        int pos = -1;
+        const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
+        const int rel0 = relLane0 + 4 * (int)(rec.y & 63);
+        int pos[4] = {-1, -1, -1, -1};
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            const bool mine = i < listCount && cis == c && sv > thCell[c];
-            const unsigned long long Bc = __ballot(mine);
-            if (mine) pos = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(Bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bc, 0));
-            run[c] += __popcll(Bc);
+            int n = 0;
+            bool in[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int sv = (rec.x >> (8 * b)) & 0xFF, rel = rel0 + b;
+                in[b] = sv > thCell[c] && rel >= c * wCell && rel < (c + 1) * wCell;
+                n += in[b] ? 1 : 0;
+            }
+            const unsigned long long B1 = __ballot(n >= 1), B2 = __ballot(n >= 2);
+            int before = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0)) +
+                         __builtin_amdgcn_mbcnt_hi((uint32_t)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B2, 0));
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (in[b]) pos[b] = before++;
+            run[c] += __popcll(B1) + __popcll(B2);
         }
-        if (pos >= 0 && pos < L.candCap) {
-            // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
-            Cand c;
-            c.x = (uint16_t)(((rec >> 11) & 63) + 3 + (c0 + cis) * L.wCell);
-            c.y = (uint16_t)((rec >> 17) + 3 + t.cellRow * L.hCell);
-            c.resp = (uint16_t)(sv - 1);
-            c.pad = 0;
-            out[pos] = c;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (pos[b] >= 0 && pos[b] < L.candCap) {
+                // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
+                Cand cnd;
+                cnd.x = (uint16_t)(rel0 + b + 3 + c0 * wCell);
+                cnd.y = (uint16_t)((rec.y >> 8) + 3 + t.cellRow * L.hCell);
+                cnd.resp = (uint16_t)(((rec.x >> (8 * b)) & 0xFF) - 1);
+                cnd.pad = 0;
+                out[pos[b]] = cnd;
+            }
         }
     }
 }
