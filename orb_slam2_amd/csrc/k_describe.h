@@ -1,15 +1,22 @@
-// k_describe.h -- K4 + K6: intensity-centroid orientation and 256-bit rBRIEF, one wavefront per keypoint (gfx950).
+// k_describe.h -- K4 + K6: intensity-centroid orientation and 256-bit rBRIEF (gfx950).
 //
 // Replaces IC_Angle / computeOrientation (reference src/ORBextractor.cc:77-104, 472-479, 851-852), computeOrbDescriptor /
 // computeDescriptors (:108-147, 1034-1041) and the output assembly of operator() (:1072-1104: pt *= scale for level > 0,
 // level-major concatenation).
 //
-// Orientation: lanes 0..30 each own one row v = lane-15 of the 749-pixel disc on the UN-blurred level and accumulate
-// (sum u*I, v*sum I) in int32; a 64-lane butterfly reduces (m10, m01); the angle is cv::fastAtan2's polynomial in
-// float32 with every operation individually rounded (the file is compiled with -ffp-contract=off).
-// Descriptor: lane i evaluates test pairs 4i..4i+3 (8 rotated taps on the blurred level); a = cos, b = sin of the angle
-// are taken in double and rounded to float (the reference calls libm cosf/sinf); tap offsets are
-// cvRound(px*b + py*a), cvRound(px*a - py*b) with un-fused float multiplies/adds and round-half-even conversion.
+// One wavefront handles 16 consecutive keypoints of a frame, in three phases, so that the per-keypoint scalar math
+// (fastAtan2, cos, sin) is done ONCE for 16 keypoints with one keypoint per lane instead of 64 times redundantly:
+//   1. moments, one keypoint at a time: the 31 disc rows of the UN-blurred level are fetched as 31 x 9 aligned dwords
+//      (5 per lane); per dword two v_dot4_u32_u8 against a mask / weight pair from an LDS table indexed by the patch's
+//      alignment (cx-15)&3 give sum(I) and sum((u+18) I) over the bytes inside the disc; m01 += v*sum(I); a DPP
+//      reduction folds the 64 lanes and the totals land in lane k of (m10, m01);
+//   2. lanes 0..15: angle = cv::fastAtan2's polynomial in float32 with every operation individually rounded, a = cos and
+//      b = sin taken in double and rounded to float (the reference calls libm cosf/sinf); the KeyPoint
+//      records are written here;
+//   3. descriptor, one keypoint at a time: the 37 x 37 window of the blurred level that the rotated taps can reach
+//      (|tap| <= round(18.38) = 18) is staged into LDS with 6 row-coalesced dword loads per lane, then lane i evaluates
+//      test pairs 4i..4i+3: tap offsets are cvRound(px*b + py*a), cvRound(px*a - py*b) with un-fused float
+//      multiplies/adds and round-half-even conversion, the 8 taps are LDS byte reads (no scattered global gathers).
 #pragma once
 #include "common.h"
 
@@ -58,10 +65,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// sum over the 64 lanes, result wave-uniform: four DPP butterfly steps give every row of 16 its sum, then four readlanes
+__device__ __forceinline__ int wave_sum_uniform(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 
 // sin and cos of x in [0, 2*pi] in double, good to ~1e-15 absolute: quadrant reduction with a two-term pi/2, then Taylor
@@ -97,106 +108,211 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double *s, double *c) {
     *c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+constexpr int kDescKpPerWave = 16;
+constexpr int kDescKpPerGroup = 4 * kDescKpPerWave;
+constexpr int kDescWinR = 18;                              // rotated taps reach at most round(hypot(13,13)) = 18 pixels
+constexpr int kDescWinRows = 2 * kDescWinR + 1;            // 37
+constexpr int kDescWinDw = 10;                             // 37 bytes + up to 3 bytes of alignment slack
+constexpr int kDescMomentDw = 31 * 9;                      // dwords of the 31 x 36 moment window
+
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint2 sMask[4][5][64];        // [alignment][dword slot][lane]: (01-mask, (u+18)-weights) of the disc
+    __shared__ uint32_t sWin[4][6 * 64];     // per wave: the blurred window, row-major, kDescWinDw dwords per row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (private L2s), so block id % 8 selects
-    // the XCD.  All blocks of frame f get ids with id % 8 == f % 8: a frame's patches (about 3 MB of level + blurred
-    // bytes, gathered ~2.5 KB per keypoint) then stay in ONE 4-MiB L2 instead of being pulled into all eight.
+    // the XCD.  All blocks of frame f get ids with id % 8 == f % 8: a frame's patches then stay in ONE 4-MiB L2 instead
+    // of being pulled into all eight.
     const int bid = blockIdx.x;
     const int f = 8 * ((bid >> 3) / a.groupsPerFrame) + (bid & 7);
     const int grp = (bid >> 3) % a.groupsPerFrame;
-    if (f >= a.nFrames) return;
-    const int i = grp * 4 + (threadIdx.x >> 6);   // keypoint index inside the frame, level-major
-    // level prefix (<= 16 entries, wave-uniform)
-    int lvl = -1, j = i, total = 0;
+    if (f >= a.nFrames) return;   // whole workgroup
+
+    for (int e = threadIdx.x; e < 4 * 5 * 64; e += 256) {
+        const int al = e / 320, rem = e - al * 320, k5 = rem >> 6, ln = rem & 63;
+        const int it = ln + 64 * k5, row = it / 9, dc = it - row * 9, v = row - kHalfPatch;
+        const int dmax = it < kDescMomentDw ? c_umax[v < 0 ? -v : v] : -1;
+        uint32_t m01 = 0, mU = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int u = 4 * dc - kHalfPatch - al + b;
+            const bool ok = u >= -dmax && u <= dmax;
+            m01 |= (ok ? 1u : 0u) << (8 * b);
+            mU |= (ok ? (uint32_t)(u + 18) : 0u) << (8 * b);
+        }
+        sMask[al][k5][ln] = make_uint2(m01, mU);
+    }
+    __syncthreads();
+
+    // ---- the wave's 16 keypoints, one per lane (lanes >= 16 mirror lanes 0..15): level, slot, geometry
+    const int iBase = grp * kDescKpPerGroup + wv * kDescKpPerWave;
+    const int i = iBase + (lane & 15);   // keypoint index inside the frame, level-major
+    int lvl = -1, j = i, total = 0, selOff = 0, pitchV = 0, bpV = 0, wV = 2 * kEdge + 1, hV = 2 * kEdge + 1;
+    unsigned long long imgV = 0, blurV = 0;
+    float scaleV = 1.f, patchV = 0.f;
     for (int l = 0; l < a.g.nlevels; l++) {
-        const int n = min(a.selCount[f * kMaxLevels + l], a.g.lv[l].selCap);
-        if (lvl < 0 && j < n) lvl = l;
+        const LevelGeom &L = a.g.lv[l];
+        const int n = min(a.selCount[f * kMaxLevels + l], L.selCap);
+        if (lvl < 0 && j < n) {
+            lvl = l;
+            wV = L.w;
+            hV = L.h;
+            selOff = L.selOff;
+            int pl;
+            imgV = (unsigned long long)level_ptr(a.s, a.g, f, l, &pl);
+            pitchV = pl;
+            blurV = (unsigned long long)(a.s.blur + (size_t)f * a.g.blurFrameBytes + L.blurOff);
+            bpV = L.pitch;
+            scaleV = L.scale;
+            patchV = L.patch;
+        }
         if (lvl < 0) j -= n;
         total += n;
     }
-    if (i == 0 && lane == 0) a.counts[f] = total;
-    if (lvl < 0 || i >= a.cap) return;
-    const LevelGeom &L = a.g.lv[lvl];
-    const SelKp kp = a.sel[(size_t)f * a.g.selFrameCap + L.selOff + j];
+    if (iBase == 0 && lane == 0) a.counts[f] = total;
+    const bool valid = lvl >= 0 && i < a.cap;
+    const int nValid = __popcll(__ballot(valid && lane < kDescKpPerWave));   // valid keypoints are a prefix of the 16
+    if (nValid == 0) return;
+    SelKp kp = {};
+    if (valid) kp = a.sel[(size_t)f * a.g.selFrameCap + selOff + j];
     // keypoints lie in [19, w-20] x [19, h-20] by construction; the clamp only makes a corrupted entry harmless (no
-    // out-of-bounds gather) instead of a GPU fault
-    const int cx = min(max((int)kp.x, kEdge), L.w - kEdge - 1), cy = min(max((int)kp.y, kEdge), L.h - kEdge - 1);
+    // out-of-bounds read) instead of a GPU fault
+    const int cxV = min(max((int)kp.x, kEdge), wV - kEdge - 1), cyV = min(max((int)kp.y, kEdge), hV - kEdge - 1);
+    const int imgLo = (int)(uint32_t)imgV, imgHi = (int)(uint32_t)(imgV >> 32);
+    const int blurLo = (int)(uint32_t)blurV, blurHi = (int)(uint32_t)(blurV >> 32);
 
-    // ---- IC_Angle on the un-blurred level: the 31 disc rows are fetched as 31 x 9 aligned dwords (5 per lane, all
-    //      in flight together); each lane folds its own bytes into (m10, m01)
-    int pitch;
-    const uint8_t *img = level_ptr(a.s, a.g, f, lvl, &pitch);
-    const int xa = (cx - kHalfPatch) & ~3;   // >= 4; xa + 35 <= cx + 20 < pitch
-    uint32_t dwv[5];
+    // ---- phase 1: moments
+    int mRow[5], mDc4[5], mV[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int it = lane + 64 * k;
-        const int row = it / 9, dc = it - row * 9;
-        dwv[k] = (it < 31 * 9) ? *reinterpret_cast<const uint32_t *>(img + (size_t)(cy - kHalfPatch + row) * pitch + xa + 4 * dc) : 0u;
+    for (int k5 = 0; k5 < 5; k5++) {
+        const int it = lane + 64 * k5, row = it / 9, dc = it - row * 9;
+        const bool in = it < kDescMomentDw;
+        mRow[k5] = in ? row : 0;          // slots past the window read a legal address and carry a zero mask
+        mDc4[k5] = in ? 4 * dc : 0;
+        mV[k5] = in ? row - kHalfPatch : 0;
     }
-    int m10 = 0, m01 = 0;
+    int m10V = 0, m01V = 0;
+    auto moment_loads = [&](int k, uint32_t (&dw)[5]) {
+        const int cx = rl(cxV, k), cy = rl(cyV, k), pitch = rl(pitchV, k);
+        const uint8_t *base = (const uint8_t *)(((unsigned long long)(uint32_t)rl(imgHi, k) << 32) | (uint32_t)rl(imgLo, k)) +
+                              (size_t)(cy - kHalfPatch) * pitch + ((cx - kHalfPatch) & ~3);   // xa >= 4; xa + 35 < pitch
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int it = lane + 64 * k;
-        const int row = it / 9, dc = it - row * 9;
-        const int v = row - kHalfPatch;
-        const int dmax = (it < 31 * 9) ? c_umax[v < 0 ? -v : v] : -1;
-        int rs = 0;
+        for (int k5 = 0; k5 < 5; k5++)
+            dw[k5] = *reinterpret_cast<const uint32_t *>(base + (__umul24((uint32_t)mRow[k5], (uint32_t)pitch) + (uint32_t)mDc4[k5]));
+    };
+    {
+        uint32_t dw[5], nx[5];
+        moment_loads(0, dw);
+        for (int k = 0; k < nValid; k++) {
+            if (k + 1 < nValid) moment_loads(k + 1, nx);
+            const int al = (rl(cxV, k) - kHalfPatch) & 3;
+            uint32_t A = 0;
+            int rsSum = 0, m01 = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int u = xa + 4 * dc + b - cx;
-            const int I = (int)((dwv[k] >> (8 * b)) & 0xFFu);
-            const int Iin = (u >= -dmax && u <= dmax) ? I : 0;
-            m10 += u * Iin;
-            rs += Iin;
+            for (int k5 = 0; k5 < 5; k5++) {
+                const uint2 mk = sMask[al][k5][lane];
+                const uint32_t rs = __builtin_amdgcn_udot4(dw[k5], mk.x, 0u, false);
+                A = __builtin_amdgcn_udot4(dw[k5], mk.y, A, false);
+                rsSum += (int)rs;
+                m01 += __mul24(mV[k5], (int)rs);
+            }
+            const int m10 = (int)A - 18 * rsSum;
+            const int s10 = wave_sum_uniform(m10), s01 = wave_sum_uniform(m01);
+            m10V = lane == k ? s10 : m10V;
+            m01V = lane == k ? s01 : m01V;
+#pragma unroll
+            for (int k5 = 0; k5 < 5; k5++) dw[k5] = nx[k5];
         }
-        m01 += v * rs;
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- rBRIEF on the blurred level
+    // ---- phase 2: one keypoint per lane
+    const float angle = fast_atan2_deg((float)m01V, (float)m10V);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     double sd, cd;
     sincos_0_2pi((double)ang, &sd, &cd);
-    const float ca = (float)cd, sb = (float)sd;
-    const uint8_t *blur = a.s.blur + (size_t)f * a.g.blurFrameBytes + L.blurOff + (size_t)cy * L.pitch + cx;
-    const int bp = L.pitch;
-    uint32_t nib = 0;
-    const uint32_t *pat32 = reinterpret_cast<const uint32_t *>(c_pattern);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const uint32_t pp = pat32[lane * 4 + t];   // (x0, y0, x1, y1) as int8
-        const float x0 = (float)(int8_t)(pp & 0xFF), y0 = (float)(int8_t)((pp >> 8) & 0xFF), x1 = (float)(int8_t)((pp >> 16) & 0xFF),
-                    y1 = (float)(int8_t)(pp >> 24);
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-        const int t0 = blur[r0 * bp + c0], t1 = blur[r1 * bp + c1];
-        nib |= (uint32_t)(t0 < t1) << t;
-    }
-    // lane i holds bits 4i..4i+3: assemble bytes (2 lanes), then dwords (8 lanes)
-    uint32_t v = nib << (4 * (lane & 7));
-    v |= __shfl_xor(v, 1);
-    v |= __shfl_xor(v, 2);
-    v |= __shfl_xor(v, 4);
-    uint8_t *dout = a.desc + ((size_t)f * a.cap + i) * 32;
-    if ((lane & 7) == 0) *reinterpret_cast<uint32_t *>(dout + (lane >> 3) * 4) = v;
-    if (lane == 0) {
+    const float caV = (float)cd, sbV = (float)sd;
+    if (valid && lane < kDescKpPerWave) {
         KeyPointOut o;
-        o.x = (float)cx;
-        o.y = (float)cy;
-        if (lvl != 0) { o.x = __fmul_rn(o.x, L.scale); o.y = __fmul_rn(o.y, L.scale); }
-        o.size = L.patch;
+        o.x = (float)cxV;
+        o.y = (float)cyV;
+        if (lvl != 0) { o.x = __fmul_rn(o.x, scaleV); o.y = __fmul_rn(o.y, scaleV); }
+        o.size = patchV;
         o.angle = angle;
         o.response = (float)kp.resp;
         o.octave = lvl;
         o.class_id = -1;
         a.kps[(size_t)f * a.cap + i] = o;
+    }
+
+    // ---- phase 3: rBRIEF on the blurred level
+    int wRow[6], wDc4[6];
+#pragma unroll
+    for (int k6 = 0; k6 < 6; k6++) {
+        const int it = lane + 64 * k6, row = it / kDescWinDw, dc = it - row * kDescWinDw;
+        const bool in = it < kDescWinRows * kDescWinDw;
+        wRow[k6] = in ? row : 0;
+        wDc4[k6] = in ? 4 * dc : 0;
+    }
+    float px0[4], py0[4], px1[4], py1[4];
+    {
+        const uint32_t *pat32 = reinterpret_cast<const uint32_t *>(c_pattern);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t pp = pat32[lane * 4 + t];   // (x0, y0, x1, y1) as int8
+            px0[t] = (float)(int8_t)(pp & 0xFF);
+            py0[t] = (float)(int8_t)((pp >> 8) & 0xFF);
+            px1[t] = (float)(int8_t)((pp >> 16) & 0xFF);
+            py1[t] = (float)(int8_t)(pp >> 24);
+        }
+    }
+    const int caI = __builtin_bit_cast(int, caV), sbI = __builtin_bit_cast(int, sbV);
+    auto window_loads = [&](int k, uint32_t (&dw)[6]) {
+        const int cx = rl(cxV, k), cy = rl(cyV, k), bp = rl(bpV, k);
+        const int xa = (cx - kDescWinR) & ~3;           // >= 0
+        const uint8_t *base = (const uint8_t *)(((unsigned long long)(uint32_t)rl(blurHi, k) << 32) | (uint32_t)rl(blurLo, k)) +
+                              (size_t)(cy - kDescWinR) * bp + xa;
+        const int dcMax = bp - 4 - xa;                  // the slack dword of a window at the right edge stays inside the row
+#pragma unroll
+        for (int k6 = 0; k6 < 6; k6++)
+            dw[k6] = *reinterpret_cast<const uint32_t *>(base + (__umul24((uint32_t)wRow[k6], (uint32_t)bp) + (uint32_t)min(wDc4[k6], dcMax)));
+    };
+    {
+        uint32_t dw[6], nx[6];
+        window_loads(0, dw);
+        const uint8_t *win = reinterpret_cast<const uint8_t *>(sWin[wv]);
+        for (int k = 0; k < nValid; k++) {
+#pragma unroll
+            for (int k6 = 0; k6 < 6; k6++) sWin[wv][lane + 64 * k6] = dw[k6];
+            if (k + 1 < nValid) window_loads(k + 1, nx);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float ca = __builtin_bit_cast(float, rl(caI, k)), sb = __builtin_bit_cast(float, rl(sbI, k));
+            const int cx = rl(cxV, k);
+            const int origin = kDescWinR * (4 * kDescWinDw) + cx - ((cx - kDescWinR) & ~3);   // byte of the keypoint in the window
+            uint32_t nib = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[t], sb), __fmul_rn(py0[t], ca)));
+                const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[t], ca), __fmul_rn(py0[t], sb)));
+                const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[t], sb), __fmul_rn(py1[t], ca)));
+                const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[t], ca), __fmul_rn(py1[t], sb)));
+                const int t0 = win[(r0 * (4 * kDescWinDw) + c0 + origin)];
+                const int t1 = win[(r1 * (4 * kDescWinDw) + c1 + origin)];
+                nib |= (uint32_t)(t0 < t1) << t;
+            }
+            // lane i holds bits 4i..4i+3: assemble dwords over groups of 8 lanes
+            uint32_t v = nib << (4 * (lane & 7));
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);
+            uint8_t *dout = a.desc + ((size_t)f * a.cap + iBase + k) * 32;
+            if ((lane & 7) == 0) *reinterpret_cast<uint32_t *>(dout + (lane >> 3) * 4) = v;
+            __builtin_amdgcn_wave_barrier();   // the next keypoint's window overwrites sWin
+#pragma unroll
+            for (int k6 = 0; k6 < 6; k6++) dw[k6] = nx[k6];
+        }
     }
 }
 

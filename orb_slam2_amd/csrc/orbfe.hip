@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -96,6 +97,10 @@ struct orbfe_extractor {
     orbfe_params p;
     int device = 0;
     hipStream_t stream = nullptr;
+    // side stream: the blur runs here while the (latency-bound, 2 workgroups per CU) quadtree runs on `stream`
+    hipStream_t stream2 = nullptr;
+    hipEvent_t evFastDone = nullptr, evBlurDone = nullptr;
+    bool overlap = true;
     // constructor tables (reference src/ORBextractor.cc:415-469)
     double scaleFactor = 1.0;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
@@ -545,14 +550,23 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         hipLaunchKernelGGL(fast_cells_kernel, dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
     }
     if (profAny) HIPCHK(hipEventRecord(e->ev[2], st));
-    // K5: blur of every level
-    hipLaunchKernelGGL(gauss7_kernel, dim3(((unsigned)e->hBlurTiles.size() + 3) / 4, F), dim3(256), 0, st, g, src,
+    const bool hostTree = quadtree_on_host(e);
+    e->lastOnHost = hostTree;
+    // K5: blur of every level.  It depends on the pyramid only and the descriptors are its only consumer, so outside
+    // per-stage profiling it runs on the side stream, started when FAST has finished: blur (VALU-bound) then shares the
+    // GPU with the quadtree (latency-bound, one workgroup per frame and level) instead of running after it.
+    const bool fork = e->overlap && !prof && !hostTree;
+    hipStream_t sb = fork ? e->stream2 : st;
+    if (fork) {
+        HIPCHK(hipEventRecord(e->evFastDone, st));
+        HIPCHK(hipStreamWaitEvent(sb, e->evFastDone, 0));
+    }
+    hipLaunchKernelGGL(gauss7_kernel, dim3(((unsigned)e->hBlurTiles.size() + 3) / 4, F), dim3(256), 0, sb, g, src,
                        (const BlurTile *)e->dBlurTiles.p, (int)e->hBlurTiles.size());
+    if (fork) HIPCHK(hipEventRecord(e->evBlurDone, sb));
     if (prof) HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipGetLastError());
 
-    const bool hostTree = quadtree_on_host(e);
-    e->lastOnHost = hostTree;
     if (hostTree) {
         rc = host_quadtree_stage(e, F);
         if (rc) return rc;
@@ -569,6 +583,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         HIPCHK(hipGetLastError());
     }
     // K4 + K6
+    if (fork) HIPCHK(hipStreamWaitEvent(st, e->evBlurDone, 0));
     if (prof) HIPCHK(hipEventRecord(e->ev[4], st));
     {
         DescribeArgs a;
@@ -581,7 +596,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.cap = cap;
         const int maxKp = std::min(g.selFrameCap, cap);
         a.nFrames = F;
-        a.groupsPerFrame = (maxKp + 3) / 4;
+        a.groupsPerFrame = (maxKp + kDescKpPerGroup - 1) / kDescKpPerGroup;
         hipLaunchKernelGGL(orient_describe_kernel, dim3((unsigned)a.groupsPerFrame * ((F + 7) / 8 * 8)), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
@@ -634,6 +649,14 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         delete e;
         return fail(ORBFE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(er));
     }
+    er = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evFastDone, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evBlurDone, hipEventDisableTiming);
+    if (er != hipSuccess) {
+        orbfe_extractor_destroy(e);
+        return fail(ORBFE_ERR_DEVICE, std::string("side stream: ") + hipGetErrorString(er));
+    }
+    if (const char *ov = getenv("ORBFE_OVERLAP")) e->overlap = atoi(ov) != 0;
     *out = e;
     return ORBFE_OK;
 }
@@ -669,6 +692,12 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamDestroy(e->stream);
     }
+    if (e->stream2) {
+        (void)hipStreamSynchronize(e->stream2);
+        (void)hipStreamDestroy(e->stream2);
+    }
+    if (e->evFastDone) (void)hipEventDestroy(e->evFastDone);
+    if (e->evBlurDone) (void)hipEventDestroy(e->evBlurDone);
     for (auto &p : e->profPool) {
         for (auto &ev : p.ev)
             if (ev) (void)hipEventDestroy(ev);

@@ -39,7 +39,61 @@
 #define A_PKMUL(r) "v_pk_mul_lo_u16 " r ", " r ", %8"
 #define A_FMA(r) "v_fma_f32 " r ", " r ", %8, %9"
 
+#define A_PKMAXF(r) "v_pk_max_f16 " r ", " r ", %8"
+#define A_PKMINF(r) "v_pk_min_f16 " r ", " r ", %8"
+#define A_MAXF32(r) "v_max_f32 " r ", " r ", %8"
+#define A_MAXF16(r) "v_max_f16 " r ", " r ", %8"
+#define A_PKADDU(r) "v_pk_add_u16 " r ", " r ", %8"
+#define A_PKSUBC(r) "v_pk_sub_u16 " r ", " r ", %8 clamp"
+#define A_AND(r) "v_and_b32 " r ", " r ", %8"
+#define A_ANDOR(r) "v_and_or_b32 " r ", " r ", %8, %9"
+#define A_ALIGNBIT(r) "v_alignbit_b32 " r ", " r ", %8, 16"
+#define A_DPP(r) "v_mov_b32_dpp " r ", " r " wave_shr:1 row_mask:0xf bank_mask:0xf"
+#define A_PKADDF(r) "v_pk_add_f16 " r ", " r ", %8"
+#define A_PKFMAF(r) "v_pk_fma_f16 " r ", " r ", %8, %9"
+#define A_MAXI(r) "v_max_i32 " r ", " r ", %8"
+#define A_MINU16(r) "v_min_u16 " r ", " r ", %8"
+#define A_SAD(r) "v_sad_u8 " r ", " r ", %8, %9"
+#define A_PKMAD(r) "v_pk_mad_u16 " r ", " r ", %8, %9"
+#define A_DOT2(r) "v_dot2_u32_u16 " r ", " r ", %8, %9"
+#define A_SUB(r) "v_sub_u32 " r ", " r ", %8"
+#define A_LSHL(r) "v_lshlrev_b32 " r ", 3, " r
+#define A_BFE(r) "v_bfe_u32 " r ", " r ", 8, 8"
+#define A_ADD3(r) "v_add3_u32 " r ", " r ", %8, %9"
+#define A_OR3(r) "v_or3_b32 " r ", " r ", %8, %9"
+#define A_CVTUB(r) "v_cvt_f32_ubyte0 " r ", " r
+#define A_PKMAXI(r) "v_pk_max_i16 " r ", " r ", %8"
+#define A_MAX3F(r) "v_max3_f32 " r ", " r ", %8, %9"
+#define A_MAX3F16(r) "v_max3_f16 " r ", " r ", %8, %9"
+#define A_PKMULF(r) "v_pk_mul_f32 " r ", " r ", %8"
+
 DEFKERNEL(k_xor, A_XOR)
+DEFKERNEL(k_pkmaxf, A_PKMAXF)
+DEFKERNEL(k_pkminf, A_PKMINF)
+DEFKERNEL(k_maxf32, A_MAXF32)
+DEFKERNEL(k_maxf16, A_MAXF16)
+DEFKERNEL(k_pkaddu, A_PKADDU)
+DEFKERNEL(k_pksubc, A_PKSUBC)
+DEFKERNEL(k_and, A_AND)
+DEFKERNEL(k_andor, A_ANDOR)
+DEFKERNEL(k_alignbit, A_ALIGNBIT)
+DEFKERNEL(k_dpp, A_DPP)
+DEFKERNEL(k_pkaddf, A_PKADDF)
+DEFKERNEL(k_pkfmaf, A_PKFMAF)
+DEFKERNEL(k_maxi, A_MAXI)
+DEFKERNEL(k_minu16, A_MINU16)
+DEFKERNEL(k_sad, A_SAD)
+DEFKERNEL(k_pkmad, A_PKMAD)
+DEFKERNEL(k_dot2, A_DOT2)
+DEFKERNEL(k_sub, A_SUB)
+DEFKERNEL(k_lshl, A_LSHL)
+DEFKERNEL(k_bfe, A_BFE)
+DEFKERNEL(k_add3, A_ADD3)
+DEFKERNEL(k_or3, A_OR3)
+DEFKERNEL(k_cvtub, A_CVTUB)
+DEFKERNEL(k_pkmaxi, A_PKMAXI)
+DEFKERNEL(k_max3f, A_MAX3F)
+DEFKERNEL(k_max3f16, A_MAX3F16)
 DEFKERNEL(k_bcnt, A_BCNT)
 DEFKERNEL(k_pkmax, A_PKMAX)
 DEFKERNEL(k_max3, A_MAX3)
@@ -64,11 +118,18 @@ int main() {
         {"v_xor_b32", k_xor}, {"v_bcnt_u32_b32", k_bcnt}, {"v_pk_max_u16", k_pkmax}, {"v_max3_u32", k_max3},
         {"v_max_u32", k_maxu}, {"v_alignbyte_b32", k_alignb}, {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4},
         {"v_med3_u32", k_med3}, {"v_mad_u32_u24", k_mad24}, {"v_mul_lo_u32", k_mullo}, {"v_lshl_or_b32", k_lshlor},
-        {"v_add_u32", k_add}, {"v_pk_mul_lo_u16", k_pkmul}, {"v_fma_f32", k_fma}};
+        {"v_add_u32", k_add}, {"v_pk_mul_lo_u16", k_pkmul}, {"v_fma_f32", k_fma},
+        {"v_pk_max_f16", k_pkmaxf}, {"v_pk_min_f16", k_pkminf}, {"v_max_f32", k_maxf32}, {"v_max_f16", k_maxf16},
+        {"v_pk_add_u16", k_pkaddu}, {"v_pk_sub_u16 clamp", k_pksubc}, {"v_and_b32", k_and}, {"v_and_or_b32", k_andor},
+        {"v_alignbit_b32", k_alignbit}, {"v_mov_b32_dpp", k_dpp}, {"v_pk_add_f16", k_pkaddf}, {"v_pk_fma_f16", k_pkfmaf},
+        {"v_max_i32", k_maxi}, {"v_min_u16", k_minu16}, {"v_sad_u8", k_sad}, {"v_pk_mad_u16", k_pkmad},
+        {"v_dot2_u32_u16", k_dot2}, {"v_sub_u32", k_sub}, {"v_lshlrev_b32", k_lshl}, {"v_bfe_u32", k_bfe},
+        {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_cvt_f32_ubyte0", k_cvtub}, {"v_pk_max_i16", k_pkmaxi},
+        {"v_max3_f32", k_max3f}, {"v_max3_f16", k_max3f16}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const int wavesPerSimd[] = {1, 2, 4, 8};
+    const int wavesPerSimd[] = {4, 8};
     printf("%-18s %6s %12s %14s\n", "instruction", "w/SIMD", "Tlane-ops/s", "cyc/instr@2.4G");
     for (auto &k : ks)
         for (int w : wavesPerSimd) {
