@@ -117,6 +117,23 @@ constexpr int kDescMomentDw = 31 * 9;                      // dwords of the 31 x
 
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
+// (int16)a * (int16)b + c
+__device__ __forceinline__ int mad_i16(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;
+// dword at (wave-uniform base) + (32-bit per-lane offset): global_load_dword with an SGPR base
+__device__ __forceinline__ uint32_t gload_u32(gptr_u8 base, uint32_t off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(base + off);
+}
+// wave-uniform global pointer from two lanes' halves
+__device__ __forceinline__ gptr_u8 gptr_from(int lo, int hi) {
+    return (gptr_u8)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     __shared__ uint2 sMask[4][5][64];        // [alignment][dword slot][lane]: (01-mask, (u+18)-weights) of the disc
     __shared__ uint32_t sWin[4][6 * 64];     // per wave: the blurred window, row-major, kDescWinDw dwords per row
@@ -191,15 +208,16 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
         mRow[k5] = in ? row : 0;          // slots past the window read a legal address and carry a zero mask
         mDc4[k5] = in ? 4 * dc : 0;
         mV[k5] = in ? row - kHalfPatch : 0;
+        asm volatile("" : "+v"(mRow[k5]), "+v"(mDc4[k5]), "+v"(mV[k5]));   // hold them, do not re-derive per keypoint
     }
     int m10V = 0, m01V = 0;
     auto moment_loads = [&](int k, uint32_t (&dw)[5]) {
         const int cx = rl(cxV, k), cy = rl(cyV, k), pitch = rl(pitchV, k);
-        const uint8_t *base = (const uint8_t *)(((unsigned long long)(uint32_t)rl(imgHi, k) << 32) | (uint32_t)rl(imgLo, k)) +
-                              (size_t)(cy - kHalfPatch) * pitch + ((cx - kHalfPatch) & ~3);   // xa >= 4; xa + 35 < pitch
+        const gptr_u8 base = gptr_from(rl(imgLo, k), rl(imgHi, k)) + (size_t)(cy - kHalfPatch) * pitch +
+                             ((cx - kHalfPatch) & ~3);   // xa >= 4; xa + 35 < pitch
 #pragma unroll
         for (int k5 = 0; k5 < 5; k5++)
-            dw[k5] = *reinterpret_cast<const uint32_t *>(base + (__umul24((uint32_t)mRow[k5], (uint32_t)pitch) + (uint32_t)mDc4[k5]));
+            dw[k5] = gload_u32(base, __umul24((uint32_t)mRow[k5], (uint32_t)pitch) + (uint32_t)mDc4[k5]);
     };
     {
         uint32_t dw[5], nx[5];
@@ -254,6 +272,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
         const bool in = it < kDescWinRows * kDescWinDw;
         wRow[k6] = in ? row : 0;
         wDc4[k6] = in ? 4 * dc : 0;
+        asm volatile("" : "+v"(wRow[k6]), "+v"(wDc4[k6]));
     }
     float px0[4], py0[4], px1[4], py1[4];
     {
@@ -271,12 +290,11 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     auto window_loads = [&](int k, uint32_t (&dw)[6]) {
         const int cx = rl(cxV, k), cy = rl(cyV, k), bp = rl(bpV, k);
         const int xa = (cx - kDescWinR) & ~3;           // >= 0
-        const uint8_t *base = (const uint8_t *)(((unsigned long long)(uint32_t)rl(blurHi, k) << 32) | (uint32_t)rl(blurLo, k)) +
-                              (size_t)(cy - kDescWinR) * bp + xa;
+        const gptr_u8 base = gptr_from(rl(blurLo, k), rl(blurHi, k)) + (size_t)(cy - kDescWinR) * bp + xa;
         const int dcMax = bp - 4 - xa;                  // the slack dword of a window at the right edge stays inside the row
 #pragma unroll
         for (int k6 = 0; k6 < 6; k6++)
-            dw[k6] = *reinterpret_cast<const uint32_t *>(base + (__umul24((uint32_t)wRow[k6], (uint32_t)bp) + (uint32_t)min(wDc4[k6], dcMax)));
+            dw[k6] = gload_u32(base, __umul24((uint32_t)wRow[k6], (uint32_t)bp) + (uint32_t)min(wDc4[k6], dcMax));
     };
     {
         uint32_t dw[6], nx[6];
@@ -291,15 +309,20 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
             const float ca = __builtin_bit_cast(float, rl(caI, k)), sb = __builtin_bit_cast(float, rl(sbI, k));
             const int cx = rl(cxV, k);
             const int origin = kDescWinR * (4 * kDescWinDw) + cx - ((cx - kDescWinR) & ~3);   // byte of the keypoint in the window
+            const int originM = origin - 0x4B400000;                                          // minus the bits of 1.5*2^23
             uint32_t nib = 0;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[t], sb), __fmul_rn(py0[t], ca)));
-                const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[t], ca), __fmul_rn(py0[t], sb)));
-                const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[t], sb), __fmul_rn(py1[t], ca)));
-                const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[t], ca), __fmul_rn(py1[t], sb)));
-                const int t0 = win[(r0 * (4 * kDescWinDw) + c0 + origin)];
-                const int t1 = win[(r1 * (4 * kDescWinDw) + c1 + origin)];
+                // cvRound by the 1.5*2^23 trick: for |x| < 2^22 the float add rounds x to the nearest-even integer and leaves
+                // it in the low mantissa bits; the tap's byte address r*40 + c + origin then takes one v_mad_i32_i16
+                // on the low halves (bits 0..15 of the sum are r as int16) plus one add
+                const float kMagic = 12582912.f;
+                const int r0 = __builtin_bit_cast(int, __fadd_rn(__fadd_rn(__fmul_rn(px0[t], sb), __fmul_rn(py0[t], ca)), kMagic));
+                const int c0 = __builtin_bit_cast(int, __fadd_rn(__fsub_rn(__fmul_rn(px0[t], ca), __fmul_rn(py0[t], sb)), kMagic));
+                const int r1 = __builtin_bit_cast(int, __fadd_rn(__fadd_rn(__fmul_rn(px1[t], sb), __fmul_rn(py1[t], ca)), kMagic));
+                const int c1 = __builtin_bit_cast(int, __fadd_rn(__fsub_rn(__fmul_rn(px1[t], ca), __fmul_rn(py1[t], sb)), kMagic));
+                const int t0 = win[mad_i16(r0, 4 * kDescWinDw, c0 + originM)];
+                const int t1 = win[mad_i16(r1, 4 * kDescWinDw, c1 + originM)];
                 nib |= (uint32_t)(t0 < t1) << t;
             }
             // lane i holds bits 4i..4i+3: assemble dwords over groups of 8 lanes
