@@ -154,7 +154,7 @@ def main():
 
     # ---- roofline of the dominant kernel (FAST): algorithmic bytes = level pixels read + 8 B per candidate written
     fast_ms = prof["stage_ms"]["fast"] / max(prof["stage_launches"]["fast"], 1)
-    cand_per_frame = prof["candidates"] / max(prof["frames"], 1)
+    cand_per_frame = sum(p["candidates"] for p in stage_profs) / max(sum(p["frames"] for p in stage_profs), 1)
     frames_per_launch = prof["frames"] / max(prof["stage_launches"]["fast"], 1)
     fast_bytes = frames_per_launch * (LEVEL_PIXELS + 8 * cand_per_frame)
     achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0

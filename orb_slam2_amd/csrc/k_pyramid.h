@@ -6,78 +6,100 @@
 //   H[r][dx] = S[r][sx]*a0 + S[r][sx+1]*a1                         (int32)
 //   D[dy][dx] = (((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2
 //
-// Work split: one 256-thread workgroup produces a 128x16 output tile.  The source footprint of the tile
-// (<= 2*128+2 columns, <= 2*16+2 rows for scale factors in (1,2]) is staged in LDS with aligned dword loads of whole
-// row segments (coalesced HBM rows), then every thread produces 8 horizontally adjacent pixels = one 8-byte store.
+// Register-sliding, no LDS: one wavefront owns 256 output columns (4 per lane) x `rows` output rows.
+//   * set-up, once per wave: each lane reads its 4 column-table entries and turns them into byte-permute selectors
+//     relative to its own source window, which starts at the first column's source pixel: for scale factors in (1,2]
+//     the 4 pixel pairs (sx, sx+1) lie inside 8 bytes;
+//   * all source rows the row block needs (<= kRszSrcRows) are fetched up front, ONE 8-byte load per lane and row at the
+//     lane's (unaligned) window address -- every load of the wave is in flight together;
+//   * a source row's horizontal pass is computed once: per pixel one v_perm_b32 builds (S[sx], S[sx+1]) as a 16-bit pair
+//     and one v_dot2_u32_u16 against (a0, a1) gives H; the previous row's H values slide along in registers;
+//   * an output row is emitted when its lower source row arrives: two 24-bit multiplies per pixel, one dword store per
+//     lane (256-B coalesced rows).
 #pragma once
 #include "common.h"
 
 namespace orbfe {
 
-constexpr int kRszTW = 128;
-constexpr int kRszTH = 16;
+constexpr int kRszStripPx = 256;     // output columns per wavefront
+constexpr int kRszSrcRows = 12;      // source rows a row block may touch (host picks `rows` accordingly)
 
 struct RszTab {      // per output column / row
     int ofs;         // source index (x: clamped to [0, sw-1]; y: unclamped as in the reference)
-    int coef;        // lo16 = weight of ofs, hi16 = weight of ofs+1  (Q11, sum ~2048)
+    int coef;        // lo16 = weight of ofs, hi16 = weight of ofs+1  (Q11, both in [0, 2048])
 };
 
 struct ResizeArgs {
     const uint8_t *src; int sPitch; size_t sFrameStride; int sw, sh;
     uint8_t *dst; int dPitch; size_t dFrameStride; int dw, dh;
-    const RszTab *xtab;   // padded to a multiple of kRszTW entries (last entry replicated)
-    const RszTab *ytab;   // padded to a multiple of kRszTH entries
-    int ldsPitch;         // bytes per staged source row (multiple of 4)
-    int ldsRows;
+    const RszTab *xtab;   // padded to a multiple of kRszStripPx entries (last entry replicated)
+    const RszTab *ytab;   // padded to a multiple of 64 entries
+    int nStrips, nRowBlocks, rows;   // rows <= 64 output rows per wavefront, chosen so that a block touches <= kRszSrcRows rows
 };
 
+struct __attribute__((packed, aligned(1))) RszWindow { uint32_t lo, hi; };
+
+typedef uint16_t rsz_u16x2 __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kRszTW, y0 = blockIdx.y * kRszTH;
-    const int f = blockIdx.z;
-    const uint8_t *src = a.src + (size_t)f * a.sFrameStride;
-    uint8_t *dst = a.dst + (size_t)f * a.dFrameStride;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.nStrips * a.nRowBlocks) return;
+    const int strip = tile % a.nStrips, rb = tile / a.nStrips;   // the 4 waves of a workgroup: neighbouring strips
+    const int f = blockIdx.y;
+    const int x0 = strip * kRszStripPx + 4 * lane;
+    const int y0 = rb * a.rows, y1 = min(y0 + a.rows, a.dh);
 
-    // source footprint of this tile
-    const int xl = min(x0 + kRszTW, a.dw) - 1, yl = min(y0 + kRszTH, a.dh) - 1;
-    const int sx0 = a.xtab[x0].ofs;
-    const int sx1 = min(a.xtab[xl].ofs + 1, a.sw - 1);
-    const int sy0 = min(max(a.ytab[y0].ofs, 0), a.sh - 1);
-    const int sy1 = min(a.ytab[yl].ofs + 1, a.sh - 1);
-    const int ax0 = sx0 & ~3;
-    const int nd = ((sx1 - ax0) >> 2) + 1;     // dwords per staged row
-    const int nr = sy1 - sy0 + 1;
-    // host guarantees nd*4 <= ldsPitch and nr <= ldsRows
-    for (int i = tid; i < nd * nr; i += 256) {
-        int r = i / nd, c = i - r * nd;
-        uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)(sy0 + r) * a.sPitch + ax0 + 4 * c);
-        *reinterpret_cast<uint32_t *>(lds + r * a.ldsPitch + 4 * c) = v;
-    }
-    __syncthreads();
-
-    const int ry = tid >> 4, cx = (tid & 15) * 8;
-    const int dy = y0 + ry;
-    if (dy >= a.dh || x0 + cx >= a.dw) return;
-    const RszTab yt = a.ytab[dy];
-    const int r0 = min(max(yt.ofs, 0), a.sh - 1) - sy0;
-    const int r1 = min(max(yt.ofs + 1, 0), a.sh - 1) - sy0;
-    const int b0 = (short)(yt.coef & 0xffff), b1 = yt.coef >> 16;
-    const uint8_t *S0 = lds + r0 * a.ldsPitch - ax0;
-    const uint8_t *S1 = lds + r1 * a.ldsPitch - ax0;
-    uint32_t out[2] = {0, 0};
+    // ---- per-lane column set-up
+    const uint4 t01 = *reinterpret_cast<const uint4 *>(a.xtab + x0), t23 = *reinterpret_cast<const uint4 *>(a.xtab + x0 + 2);
+    const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
+    const uint32_t coef[4] = {t01.y, t01.w, t23.y, t23.w};
+    const int base = min(ofs[0], a.sPitch - 8);   // the 8-byte window never leaves the row's pitch
+    uint32_t sel[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const RszTab xt = a.xtab[x0 + cx + i];
-        const int sx = xt.ofs, sxp = min(sx + 1, a.sw - 1);   // when sx == sw-1 the right weight is 0
-        const int a0 = (short)(xt.coef & 0xffff), a1 = xt.coef >> 16;
-        const int h0 = S0[sx] * a0 + S0[sxp] * a1;
-        const int h1 = S1[sx] * a0 + S1[sxp] * a1;
-        const int d = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        out[i >> 2] |= (uint32_t)(d & 0xff) << (8 * (i & 3));
+    for (int i = 0; i < 4; i++) {
+        const int o0 = ofs[i] - base, o1 = min(ofs[i] + 1, a.sw - 1) - base;   // when sx == sw-1 the right weight is 0
+        sel[i] = (uint32_t)o0 | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;
     }
-    // dPitch is a multiple of 64 and >= round_up(dw, 8): the full 8-byte store stays inside the row
-    *reinterpret_cast<uint2 *>(dst + (size_t)dy * a.dPitch + x0 + cx) = make_uint2(out[0], out[1]);
+    // ---- the row block's row-table entries, one per lane, and its source rows
+    const RszTab ytl = a.ytab[y0 + lane];
+    const int ylOfs = ytl.ofs, ylCoef = ytl.coef;
+    const int sy0 = min(max(__builtin_amdgcn_readfirstlane(ylOfs), 0), a.sh - 1);
+    const uint8_t *srcF = a.src + (size_t)f * a.sFrameStride + base;
+    RszWindow raw[kRszSrcRows];
+#pragma unroll
+    for (int j = 0; j < kRszSrcRows; j++)
+        raw[j] = *reinterpret_cast<const RszWindow *>(srcF + (size_t)min(sy0 + j, a.sh - 1) * a.sPitch);
+
+    uint8_t *dstF = a.dst + (size_t)f * a.dFrameStride + x0;
+    const bool writer = x0 < a.dw;   // dPitch is a multiple of 64 >= round_up(dw, 4): the dword store stays inside the row
+    int dy = y0;
+    uint32_t Hp[4] = {0, 0, 0, 0}, Hc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kRszSrcRows; j++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Hp[i] = Hc[i];
+            const uint32_t pr = __builtin_amdgcn_perm(raw[j].hi, raw[j].lo, sel[i]);
+            Hc[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rsz_u16x2, pr), __builtin_bit_cast(rsz_u16x2, coef[i]), 0u, false) >> 4;
+        }
+        while (dy < y1) {
+            const int yo = __builtin_amdgcn_readlane(ylOfs, dy - y0), yc = __builtin_amdgcn_readlane(ylCoef, dy - y0);
+            const int r0 = min(max(yo, 0), a.sh - 1) - sy0, r1 = min(max(yo + 1, 0), a.sh - 1) - sy0;
+            if (r1 != j) break;            // its lower source row comes later
+            const uint32_t b0 = (uint32_t)yc & 0xffffu, b1 = (uint32_t)yc >> 16;
+            const bool same = r0 == j;     // both rows clamp to the same source row (image top / bottom)
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t HA = same ? Hc[i] : Hp[i];
+                const uint32_t d = ((__umul24(b0, HA) >> 16) + (__umul24(b1, Hc[i]) >> 16) + 2u) >> 2;
+                out |= (d & 0xffu) << (8 * i);
+            }
+            if (writer) *reinterpret_cast<uint32_t *>(dstF + (size_t)dy * a.dPitch) = out;
+            dy++;
+        }
+    }
 }
 
 }  // namespace orbfe

@@ -109,12 +109,17 @@ struct orbfe_extractor {
     Geom g;
     bool haveGeom = false;
     std::vector<RszTab> hRsz;           // all levels' x and y tables
-    std::vector<int> rszLdsPitch, rszLdsRows;
+    std::vector<int> rszRows;           // output rows per wavefront of the resize kernel, per level
     std::vector<BlurTile> hBlurTiles;
     std::vector<FastTile> hFastTiles;
     DevBuf dRsz, dBlurTiles, dFastTiles;
     // per-batch workspace
-    DevBuf dPyr, dBlur, dCand, dLevelCount, dCellTab, dSel, dSelCount;
+    DevBuf dPyr, dBlur, dCand, dSel, dSelCount;
+    // status word, per-level candidate counts and the cell table share one allocation: one memset per batch zeroes them
+    DevBuf dCounters;
+    int *pStatus = nullptr, *pLevelCount = nullptr;
+    int2 *pCellTab = nullptr;
+    size_t countersBytes = 0;
     PinBuf hCand, hLevelCount, hCellTab, hSel, hSelCount;
     // single-image path
     DevBuf dImg, dKps, dDesc, dCounts;
@@ -125,7 +130,6 @@ struct orbfe_extractor {
     bool overflow = false;
     int quadtreeMode = ORBFE_QUADTREE_DEVICE;   // orbfe_set_quadtree_mode
     bool lastOnHost = false;                    // did the last call bring candidates / kept keypoints to the host
-    DevBuf dStatus;
     PinBuf hStatus;
     // optional per-stage timing with HIP events on the handle's stream (orbfe_set_profiling)
     int profiling = 0;   // 0 off, 1 every stage, 2 FAST kernel only (two events per call)
@@ -223,8 +227,7 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
     e->hRsz.clear();
     e->hBlurTiles.clear();
     e->hFastTiles.clear();
-    e->rszLdsPitch.assign(nl, 0);
-    e->rszLdsRows.assign(nl, 0);
+    e->rszRows.assign(nl, 1);
     int pyrOff = 0, blurOff = 0, cellBase = 0, candOff = 0, selOff = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom &L = g.lv[l];
@@ -282,26 +285,31 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
         if (l > 0) {
             const LevelGeom &P = g.lv[l - 1];
             L.rszOff = (int)e->hRsz.size();
-            resize_table(P.w, L.w, true, kRszTW, e->hRsz);
+            resize_table(P.w, L.w, true, kRszStripPx, e->hRsz);
             L.rszOffY = (int)e->hRsz.size();
-            resize_table(P.h, L.h, false, kRszTH, e->hRsz);
-            // LDS footprint of the worst tile
+            resize_table(P.h, L.h, false, 64, e->hRsz);
+            for (int i = 0; i < 64; i++) e->hRsz.push_back(e->hRsz.back());   // a row block reads 64 entries from its first row
+            // output rows per wavefront: the largest block whose source rows fit the kernel's register window
             const RszTab *xt = &e->hRsz[L.rszOff], *yt = &e->hRsz[L.rszOffY];
-            int maxNd = 1, maxNr = 1;
-            for (int x0 = 0; x0 < L.w; x0 += kRszTW) {
-                const int xl = std::min(x0 + kRszTW, L.w) - 1;
-                const int sx0 = xt[x0].ofs & ~3, sx1 = std::min(xt[xl].ofs + 1, P.w - 1);
-                maxNd = std::max(maxNd, ((sx1 - sx0) >> 2) + 1);
+            auto srow = [&](int v) { return std::min(std::max(v, 0), P.h - 1); };
+            int rows = 0;
+            for (int r = 16; r >= 1 && !rows; r--) {
+                bool ok = true;
+                for (int y0 = 0; y0 < L.h && ok; y0 += r) {
+                    const int yl = std::min(y0 + r, L.h) - 1;
+                    ok = srow(yt[yl].ofs + 1) - srow(yt[y0].ofs) + 1 <= kRszSrcRows;
+                }
+                if (ok) rows = r;
             }
-            for (int y0 = 0; y0 < L.h; y0 += kRszTH) {
-                const int yl = std::min(y0 + kRszTH, L.h) - 1;
-                const int sy0 = std::min(std::max(yt[y0].ofs, 0), P.h - 1), sy1 = std::min(yt[yl].ofs + 1, P.h - 1);
-                maxNr = std::max(maxNr, sy1 - sy0 + 1);
+            // the lane's 4 source pixel pairs must lie inside its 8-byte window (true for scale factors in (1, 2])
+            bool fits = rows > 0 && P.w >= 8;
+            for (int x0 = 0; x0 < L.w && fits; x0 += 4) {
+                const int last = std::min(x0 + 3, L.w - 1);
+                fits = std::min(xt[last].ofs + 1, P.w - 1) - std::min(xt[x0].ofs, round_up(P.w, 16) - 8) <= 7 &&
+                       xt[last].ofs >= xt[x0].ofs;
             }
-            e->rszLdsPitch[l] = maxNd * 4;
-            e->rszLdsRows[l] = maxNr;
-            if ((size_t)maxNd * 4 * maxNr > 60000)
-                return fail(ORBFE_ERR_UNSUPPORTED, "scale factor too large for the resize kernel's LDS tile");
+            if (!fits) return fail(ORBFE_ERR_UNSUPPORTED, "scale factor outside the resize kernel's window (1 < scale <= 2)");
+            e->rszRows[l] = rows;
         }
         for (int ty = 0; ty * kBlurRows < L.h; ty++)
             for (int tx = 0; tx * kBlurStripDw * 4 < L.w; tx++) {
@@ -334,8 +342,14 @@ int ensure_workspace(orbfe_extractor *e, int F) {
     HIPCHK(e->dPyr.ensure((size_t)F * g.pyrFrameBytes));
     HIPCHK(e->dBlur.ensure((size_t)F * g.blurFrameBytes));
     HIPCHK(e->dCand.ensure((size_t)F * g.candFrameCap * sizeof(Cand)));
-    HIPCHK(e->dLevelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
-    HIPCHK(e->dCellTab.ensure((size_t)F * g.totalCells * sizeof(int2)));
+    {
+        const size_t lcBytes = (size_t)F * kMaxLevels * sizeof(int), ctBytes = (size_t)F * g.totalCells * sizeof(int2);
+        e->countersBytes = 64 + lcBytes + ctBytes;
+        HIPCHK(e->dCounters.ensure(e->countersBytes));
+        e->pStatus = (int *)e->dCounters.p;
+        e->pLevelCount = (int *)((uint8_t *)e->dCounters.p + 64);
+        e->pCellTab = (int2 *)((uint8_t *)e->dCounters.p + 64 + lcBytes);
+    }
     HIPCHK(e->dSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
     HIPCHK(e->dSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
     HIPCHK(e->hCand.ensure((size_t)F * g.candFrameCap * sizeof(Cand)));
@@ -343,7 +357,6 @@ int ensure_workspace(orbfe_extractor *e, int F) {
     HIPCHK(e->hCellTab.ensure((size_t)F * g.totalCells * sizeof(int2)));
     HIPCHK(e->hSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
     HIPCHK(e->hSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
-    HIPCHK(e->dStatus.ensure(16));
     HIPCHK(e->hStatus.ensure(16));
     return ORBFE_OK;
 }
@@ -376,8 +389,8 @@ bool quadtree_on_host(const orbfe_extractor *e) {
 int host_quadtree_stage(orbfe_extractor *e, int F) {
     const Geom &g = e->g;
     hipStream_t st = e->stream;
-    HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(e->hCellTab.p, e->dCellTab.p, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->pLevelCount, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->hCellTab.p, e->pCellTab, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(e->hCand.p, e->dCand.p, (size_t)F * g.candFrameCap * sizeof(Cand), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     auto t0 = std::chrono::steady_clock::now();
@@ -449,9 +462,11 @@ int prof_resolve(orbfe_extractor *e) {
             e->stageLaunches[ORBFE_STAGE_DESCRIBE] += 1;
         }
         e->stageFrames += p.F;
-        const int *lc = p.counts, *sc = p.counts + (size_t)p.F * kMaxLevels;
-        for (int f = 0; f < p.F; f++)
-            for (int l = 0; l < p.nlevels; l++) { e->candTotal += lc[f * kMaxLevels + l]; e->kpTotal += sc[f * kMaxLevels + l]; }
+        if (p.mode == 1) {   // candidate / keypoint counts come back only with full profiling (mode 2 adds no copies)
+            const int *lc = p.counts, *sc = p.counts + (size_t)p.F * kMaxLevels;
+            for (int f = 0; f < p.F; f++)
+                for (int l = 0; l < p.nlevels; l++) { e->candTotal += lc[f * kMaxLevels + l]; e->kpTotal += sc[f * kMaxLevels + l]; }
+        }
     }
     e->profPending = 0;
     return ORBFE_OK;
@@ -523,15 +538,13 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.dw = L.w; a.dh = L.h;
         a.xtab = (const RszTab *)e->dRsz.p + L.rszOff;
         a.ytab = (const RszTab *)e->dRsz.p + L.rszOffY;
-        a.ldsPitch = e->rszLdsPitch[l];
-        a.ldsRows = e->rszLdsRows[l];
-        dim3 grid((L.w + kRszTW - 1) / kRszTW, (L.h + kRszTH - 1) / kRszTH, F);
-        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), (size_t)a.ldsPitch * a.ldsRows, st, a);
+        a.nStrips = (L.w + kRszStripPx - 1) / kRszStripPx;
+        a.rows = e->rszRows[l];
+        a.nRowBlocks = (L.h + a.rows - 1) / a.rows;
+        hipLaunchKernelGGL(pyr_resize_kernel, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
     }
     // K3: FAST over every cell of every level
-    HIPCHK(hipMemsetAsync(e->dLevelCount.p, 0, (size_t)F * kMaxLevels * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(e->dCellTab.p, 0, (size_t)F * g.totalCells * sizeof(int2), st));
-    HIPCHK(hipMemsetAsync(e->dStatus.p, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(e->dCounters.p, 0, e->countersBytes, st));
     if (profAny) HIPCHK(hipEventRecord(e->ev[1], st));
     {
         const int iniTh = std::min(std::max(e->p.ini_th_fast, 0), 255), minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
@@ -540,9 +553,9 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.tiles = (const FastTile *)e->dFastTiles.p;
         a.nTiles = (int)e->hFastTiles.size();
         a.cand = (Cand *)e->dCand.p;
-        a.levelCount = (int *)e->dLevelCount.p;
-        a.cellTab = (int2 *)e->dCellTab.p;
-        a.status = (int *)e->dStatus.p;
+        a.levelCount = e->pLevelCount;
+        a.cellTab = e->pCellTab;
+        a.status = e->pStatus;
         // iniTh < minTh would make the fallback a no-op in the reference too (FAST at the lower threshold runs first)
         a.iniTh = std::max(iniTh, minTh);
         a.minTh = std::min(iniTh, minTh);
@@ -575,10 +588,10 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         QuadtreeArgs a;
         a.g = g;
         a.cand = (Cand *)e->dCand.p;
-        a.levelCount = (const int *)e->dLevelCount.p;
+        a.levelCount = e->pLevelCount;
         a.sel = (SelKp *)e->dSel.p;
         a.selCount = (int *)e->dSelCount.p;
-        a.status = (int *)e->dStatus.p;
+        a.status = e->pStatus;
         hipLaunchKernelGGL(quadtree_kernel<kQtMaxNodes>, dim3(g.nlevels, F), dim3(256), sizeof(QtShared<kQtMaxNodes>), st, a);
         HIPCHK(hipGetLastError());
     }
@@ -603,8 +616,8 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     if (profAny) {
         if (prof) HIPCHK(hipEventRecord(e->ev[5], st));
         ps->hostTree = hostTree;
-        HIPCHK(hipMemcpyAsync(ps->counts, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(ps->counts + (size_t)F * kMaxLevels, e->dSelCount.p, (size_t)F * kMaxLevels * sizeof(int),
+        if (prof) HIPCHK(hipMemcpyAsync(ps->counts, e->pLevelCount, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (prof) HIPCHK(hipMemcpyAsync(ps->counts + (size_t)F * kMaxLevels, e->dSelCount.p, (size_t)F * kMaxLevels * sizeof(int),
                               hipMemcpyDeviceToHost, st));
         e->profPending++;
     }
@@ -703,8 +716,8 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
             if (ev) (void)hipEventDestroy(ev);
         if (p.counts) (void)hipHostFree(p.counts);
     }
-    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dLevelCount, &e->dCellTab, &e->dSel,
-                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->dStatus})
+    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
+                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
         b->release();
     for (PinBuf *b : {&e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
         b->release();
@@ -731,8 +744,8 @@ void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream 
 
 // after the stream has drained: fold the device status word (device quadtree) into the handle
 static int fetch_status(orbfe_extractor *e) {
-    if (!e->dStatus.p || e->lastFrames == 0) return ORBFE_OK;
-    HIPCHK(hipMemcpyAsync(e->hStatus.p, e->dStatus.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (!e->pStatus || e->lastFrames == 0) return ORBFE_OK;
+    HIPCHK(hipMemcpyAsync(e->hStatus.p, e->pStatus, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     const int st = *(const int *)e->hStatus.p;
     if (st & 1) e->overflow = true;
@@ -868,8 +881,8 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
     if (what == 2) {
         // candidates in the reference's order: read the level's dense array + cell table back and walk the cells
         const int F = e->lastFrames;
-        HIPCHK(hipMemcpy(e->hLevelCount.p, e->dLevelCount.p, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(e->hCellTab.p, e->dCellTab.p, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(e->hLevelCount.p, e->pLevelCount, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(e->hCellTab.p, e->pCellTab, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy((Cand *)e->hCand.p + (size_t)frame * g.candFrameCap + L.candOff,
                          (const Cand *)e->dCand.p + (size_t)frame * g.candFrameCap + L.candOff, (size_t)L.candCap * sizeof(Cand),
                          hipMemcpyDeviceToHost));
