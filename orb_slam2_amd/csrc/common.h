@@ -28,7 +28,7 @@ struct LevelGeom {
     float patch;            // (float)(int)(31*scale), :837
     int rszOff;             // offset of this level's x table / y table in the resize-table arrays (level >= 1)
     int rszOffY;
-    int fastCellsPerStrip;  // whole FAST cells one wavefront's strip covers (<= 8 cells, <= 58 dword columns)
+    int fastCellsPerStrip;  // whole FAST cells one wavefront's strip covers (<= 8 cells, <= 62 dword columns)
 };
 
 struct Geom {

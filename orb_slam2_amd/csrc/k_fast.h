@@ -13,8 +13,8 @@
 //     empty" (:812-816) becomes: threshold = (any survivor with S > iniTh) ? iniTh : minTh, per cell.
 //
 // One kernel, fast_cells_kernel, register-sliding like the blur: one wavefront owns (one cell row) x (a strip of whole
-// cells, <= 56 dword columns) of one level and walks down the rows.  Per row each lane loads ONE aligned dword (coalesced
-// 256-B segments) and immediately converts it to PAIR FORM: two pixels per register in 16-bit lanes, for the eight
+// cells, <= 62 dword columns) of one level and walks down the rows.  Per row each lane loads ONE dword (a coalesced 256-B
+// segment that starts 4 pixels left of the strip, at any alignment) and immediately converts it to PAIR FORM: two pixels per register in 16-bit lanes, for the eight
 // horizontal offsets -3..+4 the ring needs (2 masks/permutes, 4 DPP wave shifts for the neighbour lanes' pairs, 4
 // v_alignbit).  The last 7 rows stay in registers in that form, so the sixteen ring values of both pixel pairs of every
 // row are plain register reads.  Arc score per pair: windows k and k+1 share ring[k+1..k+8], so
@@ -32,7 +32,7 @@
 
 namespace orbfe {
 
-constexpr int kFastStripMaxDw = 60;   // writer lanes 2..61; lanes 0,1 and 62,63 are halo
+constexpr int kFastStripMaxDw = 62;   // detection lanes 1..62; lanes 0 and 63 are halo
 
 struct FastTile { uint16_t level, strip, cellRow, pad; };
 
@@ -135,9 +135,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     const int c0 = t.strip * L.fastCellsPerStrip, c1 = min(c0 + L.fastCellsPerStrip, L.nCols);
     const int Xs = kEdge + c0 * L.wCell, Xe = min(kEdge + c1 * L.wCell, w - kEdge);
     if (Xe <= Xs) return;
-    const int d = (Xs >> 2) + lane - 2;
-    const int x0 = 4 * d;
-    const int xl = min(max(x0, 0), pitch - 4);   // halo lanes beyond the row: any legal address, value unused
+    // The wave's 64 dwords start at pixel Xs-4 whatever its alignment (unaligned dword loads): lane 0 is the left halo,
+    // lanes 1..62 hold up to 248 detection pixels (8 cells of 31), lane 63 the right halo.
+    const int x0 = Xs - 4 + 4 * lane;            // >= 15
+    const int xl = min(x0, pitch - 4);           // lanes past the row: a legal address, value unused (needed pixels are < w-16)
     uint32_t ownMask = 0;                        // per byte: is the pixel a detection pixel of this strip
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     }
     const int nCells = c1 - c0;                      // <= 8
     const int wCell = L.wCell;
-    const int relLane0 = 4 * ((Xs >> 2) - 2) - Xs;   // x - Xs of byte 0 of lane 0
+    const int relLane0 = -4;                         // x - Xs of byte 0 of lane 0
     // pass A: cell maxima
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;

@@ -253,8 +253,8 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
         if (L.wCell > 64 || L.hCell > 64)   // cannot happen for 30-px cells (wCell < 60), kept as a guard for the select kernel
             return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell wider than a wavefront");
         {
-            // FAST strips: whole cells per wavefront, at most 8 cells and 58 dword columns (+ 2 halo lanes each side)
-            L.fastCellsPerStrip = std::max(1, std::min(8, (4 * 58 - 3) / L.wCell));
+            // FAST strips: whole cells per wavefront, at most 8 cells and 62 dword columns (+ 1 halo lane each side)
+            L.fastCellsPerStrip = std::max(1, std::min(8, (4 * kFastStripMaxDw) / L.wCell));
             const int nStrips = (L.nCols + L.fastCellsPerStrip - 1) / L.fastCellsPerStrip;
             for (int i = 0; i < L.nRows; i++) {
                 if (kEdge + i * L.hCell >= L.h - kEdge) continue;
