@@ -7,8 +7,10 @@
 //                             new list = reverse(children in creation order) ++ (single-point nodes, old order)
 //   size-ordered pass (:676-737) expandable nodes ranked by (point count desc, creation index desc) are split until the
 //                             list holds N nodes; new list = reverse(children) ++ (old list minus the split parents)
-// A node is a slot in the current list.  Points never move: each candidate carries its node's slot (in Cand::pad, in
-// place in HBM; every thread only ever re-reads the entries it wrote itself).  Per pass: LDS-atomic child histograms,
+// A node is a slot in the current list.  Points never move: each candidate carries its node's slot.  With up to
+// 256 * kQtRegPts candidates (the normal case) every thread keeps its candidates -- coordinates and (slot, response) --
+// in registers for the whole kernel and HBM is read exactly once; larger levels fall back to the slot stored in
+// Cand::pad, in place in HBM (every thread only ever re-reads the entries it wrote itself).  Per pass: LDS-atomic child histograms,
 // block-wide prefix sums for the new list order, relabel.  "Keep the best response per node, first wins" (:744-760) is an
 // LDS ds_max_u64 on (response << 32 | ~order) where order is the candidate's position in the reference's emission order
 // (cell row, cell column, y, x), recomputed from its coordinates -- so the unordered, atomically packed candidate array
@@ -92,36 +94,59 @@ __device__ __forceinline__ void qt_child_box(uint32_t lo, uint32_t hi, int q, ui
     *chi = (uint32_t)cx1 | ((uint32_t)cy1 << 16);
 }
 
-template <int MAXN>
-__global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
-    extern __shared__ __align__(16) uint8_t qt_lds_raw[];
-    QtShared<MAXN> &S = *reinterpret_cast<QtShared<MAXN> *>(qt_lds_raw);
+constexpr int kQtRegPts = 24;   // candidates per thread held in registers (levels with more use the HBM path)
+
+template <int MAXN, bool REG>
+__device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAXN> &S, int lvl, int f, int n) {
     const int tid = threadIdx.x;
-    const int lvl = blockIdx.x, f = blockIdx.y;
     const LevelGeom &L = a.g.lv[lvl];
     const int N = L.quota;
     int *selCount = a.selCount + f * kMaxLevels + lvl;
-    int n = a.levelCount[f * kMaxLevels + lvl];
-    if (n > L.candCap) {
-        if (tid == 0) atomicOr(a.status, 1);
-        n = L.candCap;
-    }
-    if (n == 0) {
-        if (tid == 0) *selCount = 0;
-        return;
-    }
     Cand *pts = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
     const int height = (L.h - kEdge + 3) - kMinBorder;
+    // the thread's candidates p = tid + 256 k:  xy = x | y << 16,  sr = slot | response << 16
+    uint32_t xy[REG ? kQtRegPts : 1], sr[REG ? kQtRegPts : 1];
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < kQtRegPts; k++) {
+            const int p = tid + 256 * k;
+            if (p < n) {
+                const Cand c = pts[p];
+                xy[k] = (uint32_t)c.x | ((uint32_t)c.y << 16);
+                sr[k] = (uint32_t)c.resp << 16;
+            }
+        }
+    }
+    // visit every candidate of this thread: fn(x, y, slot) may update slot
+    auto sweep = [&](auto &&fn) {
+        if (REG) {
+#pragma unroll
+            for (int k = 0; k < kQtRegPts; k++) {
+                if (tid + 256 * k < n) {
+                    int slot = (int)(sr[k] & 0xffffu);
+                    fn((int)(xy[k] & 0xffffu), (int)(xy[k] >> 16), slot);
+                    sr[k] = (sr[k] & 0xffff0000u) | (uint32_t)slot;
+                }
+            }
+        } else {
+            for (int p = tid; p < n; p += 256) {
+                const Cand c = pts[p];
+                int slot = c.pad;
+                fn((int)c.x, (int)c.y, slot);
+                if (slot != (int)c.pad) pts[p].pad = (uint16_t)slot;
+            }
+        }
+    };
 
     // ---- roots (:543-585): root r = (int)(x / hX); empty roots are dropped, list order = ascending r
     const int nIni = L.nIni;
     for (int i = tid; i < nIni; i += 256) S.child[i] = 0;
     __syncthreads();
-    for (int p = tid; p < n; p += 256) {
-        int r = (int)__fdiv_rn((float)pts[p].x, L.hX);
+    sweep([&](int x, int, int &) {
+        int r = (int)__fdiv_rn((float)x, L.hX);
         r = min(r, nIni - 1);
         atomicAdd(&S.child[r], 1);
-    }
+    });
     __syncthreads();
     if (tid == 0) {
         int slot = 0;
@@ -138,11 +163,11 @@ __global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
         S.vars[0] = slot;
     }
     __syncthreads();
-    for (int p = tid; p < n; p += 256) {
-        int r = (int)__fdiv_rn((float)pts[p].x, L.hX);
+    sweep([&](int x, int, int &slot) {
+        int r = (int)__fdiv_rn((float)x, L.hX);
         r = min(r, nIni - 1);
-        pts[p].pad = S.stay[r];
-    }
+        slot = S.stay[r];
+    });
     int cur = 0;
     int Lc = S.vars[0];
     __syncthreads();
@@ -154,15 +179,13 @@ __global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
         // ---- child histograms of every expandable slot
         for (int i = tid; i < 4 * Lc; i += 256) S.child[i] = 0;
         __syncthreads();
-        for (int p = tid; p < n; p += 256) {
-            const Cand c = pts[p];
-            const int s = c.pad;
+        sweep([&](int x, int y, int &s) {
             if (cnt[s] > 1) {
                 int mx, my;
-                const int q = qt_quadrant(bLo[s], bHi[s], c.x, c.y, &mx, &my);
+                const int q = qt_quadrant(bLo[s], bHi[s], x, y, &mx, &my);
                 atomicAdd(&S.child[4 * s + q], 1);
             }
-        }
+        });
         __syncthreads();
 
         int rStar = 0x7fffffff;   // size-ordered: last rank that is split
@@ -252,20 +275,16 @@ __global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
         for (int o = 32; o > 0; o >>= 1) nExp += __shfl_xor(nExp, o);
         if ((tid & 63) == 0) S.scanTmp[4 + (tid >> 6)] = nExp;
         // ---- relabel the points
-        for (int p = tid; p < n; p += 256) {
-            const Cand c = pts[p];
-            const int s = c.pad;
+        sweep([&](int x, int y, int &s) {
             const bool split = sized ? (S.rankOf[s] <= rStar) : (cnt[s] > 1);
-            int ns;
             if (split) {
                 int mx, my;
-                const int q = qt_quadrant(bLo[s], bHi[s], c.x, c.y, &mx, &my);
-                ns = C - 1 - S.cidx[4 * s + q];
+                const int q = qt_quadrant(bLo[s], bHi[s], x, y, &mx, &my);
+                s = C - 1 - S.cidx[4 * s + q];
             } else {
-                ns = C + stayFlag[s];
+                s = C + stayFlag[s];
             }
-            pts[p].pad = (uint16_t)ns;
-        }
+        });
         // ---- write the next generation
         uint32_t *nLo = S.boxLo[cur ^ 1], *nHi = S.boxHi[cur ^ 1];
         __syncthreads();   // perParent (aliases cnt[cur^1]) fully consumed before it is overwritten
@@ -307,14 +326,23 @@ __global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
     unsigned long long *best = reinterpret_cast<unsigned long long *>(S.child);
     for (int i = tid; i < Lc; i += 256) best[i] = 0ull;
     __syncthreads();
-    for (int p = tid; p < n; p += 256) {
-        const Cand c = pts[p];
+    auto vote = [&](int x, int y, int slot, uint32_t resp) {
         // reference emission order: cell row, cell column, then row-major inside the cell (src/ORBextractor.cc:789-829)
-        const int ci = (c.y - 3) / L.hCell, cj = (c.x - 3) / L.wCell;
-        const int yin = c.y - 3 - ci * L.hCell, xin = c.x - 3 - cj * L.wCell;
+        const int ci = (y - 3) / L.hCell, cj = (x - 3) / L.wCell;
+        const int yin = y - 3 - ci * L.hCell, xin = x - 3 - cj * L.wCell;
         const uint32_t order = ((uint32_t)(ci * L.nCols + cj) << 12) | ((uint32_t)yin << 6) | (uint32_t)xin;
-        const unsigned long long key = ((unsigned long long)(c.resp + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
-        atomicMax(&best[c.pad], key);
+        const unsigned long long key = ((unsigned long long)(resp + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
+        atomicMax(&best[slot], key);
+    };
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < kQtRegPts; k++)
+            if (tid + 256 * k < n) vote((int)(xy[k] & 0xffffu), (int)(xy[k] >> 16), (int)(sr[k] & 0xffffu), sr[k] >> 16);
+    } else {
+        for (int p = tid; p < n; p += 256) {
+            const Cand c = pts[p];
+            vote(c.x, c.y, c.pad, c.resp);
+        }
     }
     __syncthreads();
     SelKp *out = a.sel + (size_t)f * a.g.selFrameCap + L.selOff;
@@ -331,6 +359,28 @@ __global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
         out[i] = k;
     }
     if (tid == 0) *selCount = min(Lc, L.selCap);
+}
+
+template <int MAXN>
+__global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
+    extern __shared__ __align__(16) uint8_t qt_lds_raw[];
+    QtShared<MAXN> &S = *reinterpret_cast<QtShared<MAXN> *>(qt_lds_raw);
+    const int tid = threadIdx.x;
+    const int lvl = blockIdx.x, f = blockIdx.y;
+    const LevelGeom &L = a.g.lv[lvl];
+    int n = a.levelCount[f * kMaxLevels + lvl];
+    if (n > L.candCap) {
+        if (tid == 0) atomicOr(a.status, 1);
+        n = L.candCap;
+    }
+    if (n == 0) {
+        if (tid == 0) a.selCount[f * kMaxLevels + lvl] = 0;
+        return;
+    }
+    if (n <= 256 * kQtRegPts)
+        quadtree_run<MAXN, true>(a, S, lvl, f, n);
+    else
+        quadtree_run<MAXN, false>(a, S, lvl, f, n);
 }
 
 }  // namespace orbfe

@@ -592,7 +592,15 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.sel = (SelKp *)e->dSel.p;
         a.selCount = (int *)e->dSelCount.p;
         a.status = e->pStatus;
-        hipLaunchKernelGGL(quadtree_kernel<kQtMaxNodes>, dim3(g.nlevels, F), dim3(256), sizeof(QtShared<kQtMaxNodes>), st, a);
+        // node tables sized to what the largest level needs: smaller tables = more trees resident per CU
+        int need = 0;
+        for (int l = 0; l < g.nlevels; l++) need = std::max(need, std::max(g.lv[l].quota + 3, 4 * g.lv[l].nIni));
+        if (need <= 256)
+            hipLaunchKernelGGL(quadtree_kernel<256>, dim3(g.nlevels, F), dim3(256), sizeof(QtShared<256>), st, a);
+        else if (need <= 512)
+            hipLaunchKernelGGL(quadtree_kernel<512>, dim3(g.nlevels, F), dim3(256), sizeof(QtShared<512>), st, a);
+        else
+            hipLaunchKernelGGL(quadtree_kernel<kQtMaxNodes>, dim3(g.nlevels, F), dim3(256), sizeof(QtShared<kQtMaxNodes>), st, a);
         HIPCHK(hipGetLastError());
     }
     // K4 + K6
