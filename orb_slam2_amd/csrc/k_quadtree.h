@@ -94,6 +94,13 @@ __device__ __forceinline__ void qt_child_box(uint32_t lo, uint32_t hi, int q, ui
     *chi = (uint32_t)cx1 | ((uint32_t)cy1 << 16);
 }
 
+#ifdef ORBFE_QT_TIMING
+__device__ unsigned long long g_qtTimes[256];
+#define QT_MARK(i) do { if (threadIdx.x == 0 && lvl == 0 && f == 0) g_qtTimes[(i)] = wall_clock64(); } while (0)
+#else
+#define QT_MARK(i) do {} while (0)
+#endif
+
 constexpr int kQtRegPts = 24;   // candidates per thread held in registers (levels with more use the HBM path)
 
 template <int MAXN, bool REG>
@@ -102,6 +109,7 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
     const LevelGeom &L = a.g.lv[lvl];
     const int N = L.quota;
     int *selCount = a.selCount + f * kMaxLevels + lvl;
+    QT_MARK(0);
     Cand *pts = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
     const int height = (L.h - kEdge + 3) - kMinBorder;
     // the thread's candidates p = tid + 256 k:  xy = x | y << 16,  sr = slot | response << 16
@@ -109,14 +117,45 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
     if (REG) {
 #pragma unroll
         for (int k = 0; k < kQtRegPts; k++) {
+            // un-predicated loads (clamped index) so that all of them are in flight together; candidates past n become
+            // slot 0 at (0,0), which keeps the un-predicated table reads of the sweeps legal
             const int p = tid + 256 * k;
-            if (p < n) {
-                const Cand c = pts[p];
-                xy[k] = (uint32_t)c.x | ((uint32_t)c.y << 16);
-                sr[k] = (uint32_t)c.resp << 16;
-            }
+            const Cand c = pts[min(p, n - 1)];
+            xy[k] = p < n ? ((uint32_t)c.x | ((uint32_t)c.y << 16)) : 0u;
+            sr[k] = p < n ? ((uint32_t)c.resp << 16) : 0u;
         }
     }
+    // Register path: candidates are visited in chunks of 4.  `gather` does the chunk's LDS table reads un-predicated
+    // (they are issued together, one wait), `apply` then does the predicated part.  HBM path: one candidate at a time.
+    auto sweep2 = [&](auto &&gather, auto &&apply) {
+        if (REG) {
+#pragma unroll
+            for (int c0 = 0; c0 < kQtRegPts; c0 += 4) {
+                if (256 * c0 < n) {   // workgroup-uniform
+                    decltype(gather(0, 0, 0)) G[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        G[j] = gather((int)(xy[c0 + j] & 0xffffu), (int)(xy[c0 + j] >> 16), (int)(sr[c0 + j] & 0xffffu));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int k = c0 + j;
+                        const bool valid = tid + 256 * k < n;
+                        int slot = (int)(sr[k] & 0xffffu);
+                        apply(valid, (int)(xy[k] & 0xffffu), (int)(xy[k] >> 16), slot, G[j]);
+                        sr[k] = (sr[k] & 0xffff0000u) | (valid ? (uint32_t)slot : 0u);
+                    }
+                }
+            }
+        } else {
+            for (int p = tid; p < n; p += 256) {
+                const Cand c = pts[p];
+                int slot = c.pad;
+                const auto G = gather((int)c.x, (int)c.y, slot);
+                apply(true, (int)c.x, (int)c.y, slot, G);
+                if (slot != (int)c.pad) pts[p].pad = (uint16_t)slot;
+            }
+        }
+    };
     // visit every candidate of this thread: fn(x, y, slot) may update slot
     auto sweep = [&](auto &&fn) {
         if (REG) {
@@ -142,11 +181,29 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
     const int nIni = L.nIni;
     for (int i = tid; i < nIni; i += 256) S.child[i] = 0;
     __syncthreads();
-    sweep([&](int x, int, int &) {
-        int r = (int)__fdiv_rn((float)x, L.hX);
-        r = min(r, nIni - 1);
-        atomicAdd(&S.child[r], 1);
-    });
+    if (REG) {
+        // root of every candidate into its slot field, then one wave-wide count per root (a few roots, thousands of
+        // candidates: per-candidate LDS atomics would all hit the same few words)
+#pragma unroll
+        for (int k = 0; k < kQtRegPts; k++) {
+            const int r = min((int)__fdiv_rn((float)(xy[k] & 0xffffu), L.hX), nIni - 1);
+            sr[k] = (sr[k] & 0xffff0000u) | (uint32_t)r;
+        }
+        for (int r = 0; r < nIni; r++) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < kQtRegPts; k++) c += (tid + 256 * k < n && (int)(sr[k] & 0xffffu) == r) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if ((tid & 63) == 0 && c) atomicAdd(&S.child[r], c);
+        }
+    } else {
+        sweep([&](int x, int, int &) {
+            int r = (int)__fdiv_rn((float)x, L.hX);
+            r = min(r, nIni - 1);
+            atomicAdd(&S.child[r], 1);
+        });
+    }
     __syncthreads();
     if (tid == 0) {
         int slot = 0;
@@ -173,32 +230,46 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
     __syncthreads();
 
     bool sized = false;   // false: breadth passes, true: size-ordered passes
+    QT_MARK(1);
     for (int iter = 0; iter < 64; iter++) {
+        QT_MARK(8 + iter * 8);
         const uint32_t *bLo = S.boxLo[cur], *bHi = S.boxHi[cur];
         const int *cnt = S.cnt[cur];
         // ---- child histograms of every expandable slot
         for (int i = tid; i < 4 * Lc; i += 256) S.child[i] = 0;
         __syncthreads();
-        sweep([&](int x, int y, int &s) {
-            if (cnt[s] > 1) {
-                int mx, my;
-                const int q = qt_quadrant(bLo[s], bHi[s], x, y, &mx, &my);
-                atomicAdd(&S.child[4 * s + q], 1);
-            }
-        });
+        struct HistG { uint32_t lo, hi; int c; };
+        sweep2([&](int, int, int s) { return HistG{bLo[s], bHi[s], cnt[s]}; },
+               [&](bool valid, int x, int y, int &s, const HistG &G) {
+                   if (valid && G.c > 1) {
+                       int mx, my;
+                       const int q = qt_quadrant(G.lo, G.hi, x, y, &mx, &my);
+                       atomicAdd(&S.child[4 * s + q], 1);
+                   }
+               });
         __syncthreads();
 
+        QT_MARK(8 + iter * 8 + 1);
         int rStar = 0x7fffffff;   // size-ordered: last rank that is split
         if (sized) {
             // ---- rank expandable slots by (count desc, slot asc) == (count, creation index) walked from the back
+            // key = (count << 11 | 2047 - slot) for expandable slots, 0 otherwise: rank = number of larger keys
+            int *keys = reinterpret_cast<int *>(S.cidx);   // 2*MAXN ints, not in use before the creation-order step
+            const int Lc4 = (Lc + 3) & ~3;
+            for (int s = tid; s < Lc4; s += 256) {
+                const int c = s < Lc ? cnt[s] : 0;
+                keys[s] = c > 1 ? ((c << 11) | (2047 - s)) : 0;
+            }
+            __syncthreads();
             for (int s = tid; s < Lc; s += 256) {
                 int rk = 0xFFFF;
-                const int c = cnt[s];
-                if (c > 1) {
+                const int key = keys[s];
+                if (key) {
                     rk = 0;
-                    for (int t = 0; t < Lc; t++) {
-                        const int ct = cnt[t];
-                        rk += (ct > 1) && (ct > c || (ct == c && t < s));
+#pragma unroll 4
+                    for (int t = 0; t < Lc4; t += 4) {
+                        const int4 v = *reinterpret_cast<const int4 *>(keys + t);
+                        rk += (v.x > key) + (v.y > key) + (v.z > key) + (v.w > key);
                     }
                     S.slotByRank[rk] = (uint16_t)s;
                     const int ne = (S.child[4 * s] > 0) + (S.child[4 * s + 1] > 0) + (S.child[4 * s + 2] > 0) + (S.child[4 * s + 3] > 0);
@@ -206,6 +277,7 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
                 }
                 S.rankOf[s] = (uint16_t)rk;
             }
+            __syncthreads();   // keys (aliasing cidx) are dead from here
             if (tid == 0) S.vars[1] = 0x7fffffff;
             __syncthreads();
             int E = 0;   // number of expandable slots: they occupy ranks 0..E-1
@@ -230,6 +302,7 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
         //      cidx is indexed by 4*slot+q in both cases; the scan runs over the creation sequence.
         //      Use S.gain as the scan scratch is not possible (needed above), so scan in S.child's shadow: cidx via ints
         //      in a temporary view of `stay`/... -> keep it simple: scan over an int array aliased on the next box buffer.
+        QT_MARK(8 + iter * 8 + 2);
         int *scanBuf = reinterpret_cast<int *>(S.boxLo[cur ^ 1]);   // 4*MAXN bytes = MAXN ints: not enough for 4*Lc flags
         (void)scanBuf;
         // flags are packed per parent: nonempty-children count (0..4) per creation position, then expanded per child
@@ -257,6 +330,7 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
                 }
             }
         }
+        QT_MARK(8 + iter * 8 + 3);
         // ---- nodes that stay: single-point nodes (breadth) / everything not split (size-ordered), old order
         int *stayFlag = S.gain;   // free again
         for (int s = tid; s < Lc; s += 256) {
@@ -274,17 +348,18 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nExp += __shfl_xor(nExp, o);
         if ((tid & 63) == 0) S.scanTmp[4 + (tid >> 6)] = nExp;
+        QT_MARK(8 + iter * 8 + 4);
         // ---- relabel the points
-        sweep([&](int x, int y, int &s) {
-            const bool split = sized ? (S.rankOf[s] <= rStar) : (cnt[s] > 1);
-            if (split) {
-                int mx, my;
-                const int q = qt_quadrant(bLo[s], bHi[s], x, y, &mx, &my);
-                s = C - 1 - S.cidx[4 * s + q];
-            } else {
-                s = C + stayFlag[s];
-            }
-        });
+        struct RelG { uint32_t lo, hi; int key, stay; };
+        sweep2([&](int, int, int s) { return RelG{bLo[s], bHi[s], sized ? (int)S.rankOf[s] : cnt[s], stayFlag[s]}; },
+               [&](bool, int x, int y, int &s, const RelG &G) {
+                   const bool split = sized ? (G.key <= rStar) : (G.key > 1);
+                   int mx, my;
+                   const int q = qt_quadrant(G.lo, G.hi, x, y, &mx, &my);
+                   const int ci = S.cidx[4 * s + q];   // stale for nodes that are not split: read but not used
+                   s = split ? C - 1 - ci : C + G.stay;
+               });
+        QT_MARK(8 + iter * 8 + 5);
         // ---- write the next generation
         uint32_t *nLo = S.boxLo[cur ^ 1], *nHi = S.boxHi[cur ^ 1];
         __syncthreads();   // perParent (aliases cnt[cur^1]) fully consumed before it is overwritten
@@ -317,18 +392,25 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
         Lc = newL;
         cur ^= 1;
         __syncthreads();
+        QT_MARK(8 + iter * 8 + 6);
+#ifdef ORBFE_QT_TIMING
+        if (threadIdx.x == 0 && lvl == 0 && f == 0) { g_qtTimes[8 + iter * 8 + 7] = ((unsigned long long)Lc << 32) | (sized ? 1u : 0u); g_qtTimes[2] = iter + 1; }
+#endif
         // ---- stop / switch rule (:669-673, :734)
         if (Lc >= N || Lc == prevL) break;
         if (!sized && Lc + 3 * nExp > N) sized = true;
     }
 
+    QT_MARK(3);
     // ---- best response per node, first in reference order wins (:744-760)
     unsigned long long *best = reinterpret_cast<unsigned long long *>(S.child);
     for (int i = tid; i < Lc; i += 256) best[i] = 0ull;
     __syncthreads();
+    // a / b == mulhi(a, ceil(2^32 / b)) for a * b < 2^32 (coordinates < 65536, cells of 2..64 px)
+    const uint32_t rcpH = (uint32_t)(((1ull << 32) + L.hCell - 1) / L.hCell), rcpW = (uint32_t)(((1ull << 32) + L.wCell - 1) / L.wCell);
     auto vote = [&](int x, int y, int slot, uint32_t resp) {
         // reference emission order: cell row, cell column, then row-major inside the cell (src/ORBextractor.cc:789-829)
-        const int ci = (y - 3) / L.hCell, cj = (x - 3) / L.wCell;
+        const int ci = (int)__umulhi((uint32_t)(y - 3), rcpH), cj = (int)__umulhi((uint32_t)(x - 3), rcpW);
         const int yin = y - 3 - ci * L.hCell, xin = x - 3 - cj * L.wCell;
         const uint32_t order = ((uint32_t)(ci * L.nCols + cj) << 12) | ((uint32_t)yin << 6) | (uint32_t)xin;
         const unsigned long long key = ((unsigned long long)(resp + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - order);
@@ -359,6 +441,10 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
         out[i] = k;
     }
     if (tid == 0) *selCount = min(Lc, L.selCap);
+    QT_MARK(4);
+#ifdef ORBFE_QT_TIMING
+    if (threadIdx.x == 0 && lvl == 0 && f == 0) g_qtTimes[5] = n;
+#endif
 }
 
 template <int MAXN>

@@ -748,6 +748,12 @@ int orbfe_get_tables(const orbfe_extractor *e, float *scale, float *inv_scale, f
     return ORBFE_OK;
 }
 
+#ifdef ORBFE_QT_TIMING
+int orbfe_debug_qt_times(unsigned long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(orbfe::g_qtTimes), sizeof(unsigned long long) * std::min(n, 256)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream : nullptr; }
 
 // after the stream has drained: fold the device status word (device quadtree) into the handle
