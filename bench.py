@@ -53,17 +53,100 @@ def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
                       f"oracle built -O3 -march=x86-64-v3 -ffp-contract=off; {kps / n:.0f} keypoints/frame"}
 
 
+def other_configs(local_rank, dev):
+    """Side measurements for BASELINE.json configs[1] (TUM 640x480, per-frame latency), configs[2] (KITTI stereo pair +
+    row-band search) and the EuRoC resolution.  Rank 0, one GPU; a few hundred milliseconds each; not part of `value`."""
+    import torch
+    from orb_slam2_amd import capi, synth
+    out = {}
+
+    def batch_fps(W, H, nfeat, B, steps=6):
+        stride = (W + 63) // 64 * 64
+        uniq = synth.frame_sequence(8, W, H, first=900)
+        host = np.zeros((B, H, stride), np.uint8)
+        for i in range(B):
+            host[i, :, :W] = uniq[i % 8]
+        frames = torch.from_numpy(host).to(dev)
+        cap = nfeat + 64
+        kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        ex = capi.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+        call = lambda n, sync: ex.extract_batch_device(frames.data_ptr(), n, W, H, stride, stride * H, kps.data_ptr(),
+                                                       desc.data_ptr(), cnt.data_ptr(), cap, sync=sync)
+        for _ in range(2):
+            call(B, True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call(B, False)
+        ex.synchronize()
+        fps = B * steps / (time.perf_counter() - t0)
+        lat = []
+        for _ in range(30):          # one frame already in HBM, synchronous call
+            t0 = time.perf_counter()
+            call(1, True)
+            lat.append(time.perf_counter() - t0)
+        host_lat = []
+        img = np.ascontiguousarray(uniq[0])
+        ex(img)
+        for _ in range(30):          # host image in, host keypoints + descriptors out (PCIe both ways)
+            t0 = time.perf_counter()
+            ex(img)
+            host_lat.append(time.perf_counter() - t0)
+        return {"frames_per_s_batched": round(fps, 1), "batch": B, "features": nfeat,
+                "latency_ms_device_resident_frame": round(float(np.median(lat)) * 1e3, 4),
+                "latency_ms_host_image_to_host_result": round(float(np.median(host_lat)) * 1e3, 4),
+                "keypoints_per_frame": round(float(cnt.float().mean().item()), 1)}
+
+    out["tum_640x480_1000kp"] = batch_fps(640, 480, 1000, 256)
+    out["euroc_752x480_1000kp"] = batch_fps(752, 480, 1000, 256)
+
+    # KITTI stereo pair: left + right extraction as one 2-frame batch, then the row-band Hamming search on the device
+    W, H, nfeat = 1241, 376, NFEATURES
+    stride = (W + 63) // 64 * 64
+    left, right = synth.stereo_pair(W, H, synth.BASE_SEED + 50)
+    host = np.zeros((2, H, stride), np.uint8)
+    host[0, :, :W], host[1, :, :W] = left, right
+    frames = torch.from_numpy(host).to(dev)
+    cap = nfeat + 64
+    kps = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    bd, bi = (torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(2))
+    ex = capi.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+    m = capi.ORBmatcher(device=local_rank)
+    sf = ex.GetScaleFactors()
+    max_d = float(np.float32(386.1448) / np.float32(0.5371657))      # KITTI00-02.yaml: bf / b
+    lat = []
+    for it in range(33):
+        t0 = time.perf_counter()
+        ex.extract_batch_device(frames.data_ptr(), 2, W, H, stride, stride * H, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
+                                cap, sync=True)
+        n = cnt.cpu().numpy()        # the matcher needs the counts on the host, as Frame::ComputeStereoMatches does
+        m.stereo_rowband_device(kps[0].data_ptr(), desc[0].data_ptr(), int(n[0]), kps[1].data_ptr(), desc[1].data_ptr(), int(n[1]),
+                                sf, H, 0.0, max_d, bd.data_ptr(), bi.data_ptr(), sync=True)
+        if it >= 3:
+            lat.append(time.perf_counter() - t0)
+    out["kitti_stereo_pair_1241x376_2000kp"] = {
+        "latency_ms_pair_extract_plus_rowband": round(float(np.median(lat)) * 1e3, 4),
+        "pairs_per_s_sequential": round(1.0 / float(np.median(lat)), 1),
+        "left_keypoints": int(n[0]), "right_keypoints": int(n[1]),
+        "rowband_matches_below_75": int((bd[:int(n[0])] < 75).sum().item())}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step and rank")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step and rank")
     ap.add_argument("--handles", type=int, default=1,
                     help="extractor handles (one HIP stream each) the step's frames are split over; the reference itself "
                          "runs two extractor objects concurrently (src/Frame.cc:78-81)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the TUM / EuRoC / stereo side measurements")
     args = ap.parse_args()
 
     import torch
@@ -159,15 +242,16 @@ def main():
     fast_bytes = frames_per_launch * (LEVEL_PIXELS + 8 * cand_per_frame)
     achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
     # traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at 64 frames per launch
-    # (profiles/r1_pmc_fetch_write_summary.txt): 2 x 57.1 MB fetched (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md) +
-    # 6.8 MB written = 1.89 MB per frame; scaled to the frames one launch of this run processes.
-    traffic = int(frames_per_launch * (2 * 57105.3 + 6755.7) * 1024 / 64)
+    # (profiles/r1c_pmc_summary.txt): 2 x 53.4 MB fetched (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md) +
+    # 6.7 MB written = 1.82 MB per frame; scaled to the frames one launch of this run processes.
+    traffic = int(frames_per_launch * (2 * 53420.0 + 6710.4) * 1024 / 64)
     roofline = {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "ms_per_launch": round(fast_ms, 4), "algorithmic_bytes_per_launch": int(fast_bytes),
                 "frames_per_launch": frames_per_launch,
-                "note": "FAST is integer-VALU-bound (~250 packed min/max per 4 pixels at the measured 38 T lane-ops/s), not "
-                        "HBM-bound; ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
+                "note": "FAST is integer-VALU-bound, not HBM-bound: ~272 VALU instructions per wave and pixel row (208 of them "
+                        "v_pk_max/min_u16 at the measured 4.15 cycles), SQ_INSTS_VALU says 83 % issue utilisation "
+                        "(profiles/r1c_pmc_summary.txt); ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
                         "--handles > 1 the other handle's kernels run concurrently and inflate it); stage_ms_per_step "
                         "comes from 5 extra un-timed steps with events around every stage",
                 "stage_ms_per_step": stages}
@@ -222,6 +306,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(uniq)
 
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = other_configs(local_rank, dev)
+
     if rank == 0:
         out = {
             "metric": "orb_extract_frames_per_sec_1241x376_2000kp_8lvl", "value": round(fps, 2), "unit": "frames/s",
@@ -231,7 +319,7 @@ def main():
                                    "8 levels, scale 1.2, FAST 20/7 (BASELINE.json configs[0] shape, configs[3] batching)",
                        "frames_per_step_per_gpu": B, "handles": nh, "keypoints_per_frame": round(kp_per_frame, 1),
                        "parallelism": f"frames sharded over {world} gpu(s), no collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "hamming": hamming,
+            "roofline": roofline, "cpu_baseline": cpu, "hamming": hamming, "other_configs": extras,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -123,7 +123,7 @@ struct orbfe_extractor {
     PinBuf hCand, hLevelCount, hCellTab, hSel, hSelCount;
     // single-image path
     DevBuf dImg, dKps, dDesc, dCounts;
-    PinBuf hKps, hDesc, hCounts;
+    PinBuf hImg, hKps, hDesc, hCounts;
     // last call (for orbfe_pyramid_level / orbfe_debug_stage)
     ImgSrc last{};
     int lastFrames = 0;
@@ -727,7 +727,7 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
     for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
         b->release();
-    for (PinBuf *b : {&e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
+    for (PinBuf *b : {&e->hImg, &e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
         b->release();
     delete e;
     return ORBFE_OK;
@@ -757,16 +757,20 @@ int orbfe_debug_qt_times(unsigned long long *out, int n) {
 void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream : nullptr; }
 
 // after the stream has drained: fold the device status word (device quadtree) into the handle
+static int eval_status(orbfe_extractor *e) {
+    const int st = *(const int *)e->hStatus.p;
+    if (st & 1) e->overflow = true;
+    if (st & 2) return fail(ORBFE_ERR_CAPACITY, "quadtree node table overflow");
+    if (st & 4) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list of a strip overflowed (more than 1024 lane records in 8 cells)");
+    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
+    return ORBFE_OK;
+}
+
 static int fetch_status(orbfe_extractor *e) {
     if (!e->pStatus || e->lastFrames == 0) return ORBFE_OK;
     HIPCHK(hipMemcpyAsync(e->hStatus.p, e->pStatus, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    const int st = *(const int *)e->hStatus.p;
-    if (st & 1) e->overflow = true;
-    if (st & 2) return fail(ORBFE_ERR_CAPACITY, "quadtree node table overflow");
-    if (st & 4) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list of a strip overflowed (more than 2048 local maxima in 8 cells)");
-    if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
-    return ORBFE_OK;
+    return eval_status(e);
 }
 
 int orbfe_synchronize(orbfe_extractor *e) {
@@ -820,22 +824,29 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
     HIPCHK(e->hKps.ensure((size_t)icap * sizeof(KeyPointOut)));
     HIPCHK(e->hDesc.ensure((size_t)icap * 32));
     HIPCHK(e->hCounts.ensure(sizeof(int) * 4));
-    HIPCHK(hipMemcpy2DAsync(e->dImg.p, pitch, img, stride, w, h, hipMemcpyHostToDevice, e->stream));
+    // the image goes through a pinned staging buffer in the device pitch: one DMA instead of a pitched copy from
+    // pageable memory (which the runtime splits into one transfer per row)
+    HIPCHK(e->hImg.ensure(fs));
+    for (int y = 0; y < h; y++) memcpy((uint8_t *)e->hImg.p + (size_t)y * pitch, img + (size_t)y * stride, (size_t)w);
+    HIPCHK(hipMemcpyAsync(e->dImg.p, e->hImg.p, fs, hipMemcpyHostToDevice, e->stream));
     rc = run_batch(e, (const uint8_t *)e->dImg.p, 1, w, h, pitch, round_up((int)fs, 16), (orbfe_keypoint *)e->dKps.p,
                    (uint8_t *)e->dDesc.p, (int32_t *)e->dCounts.p, icap);
     if (rc) return rc;
+    // count, keypoints and descriptors come back together (at most selFrameCap entries, ~130 KB): one synchronisation
     HIPCHK(hipMemcpyAsync(e->hCounts.p, e->dCounts.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->hKps.p, e->dKps.p, (size_t)icap * sizeof(KeyPointOut), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->hDesc.p, e->dDesc.p, (size_t)icap * 32, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->hStatus.p, e->pStatus, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     const int n = *(int *)e->hCounts.p;
     if (n_out) *n_out = n;
-    rc = fetch_status(e);
+    rc = eval_status(e);
     if (rc) return rc;
     if (n > cap) return fail(ORBFE_ERR_CAPACITY, "keypoint buffer too small");
     if (n == 0) return ORBFE_OK;
     if (!kps || !desc32) return fail(ORBFE_ERR_ARG, "null output");
-    HIPCHK(hipMemcpyAsync(kps, e->dKps.p, (size_t)n * sizeof(KeyPointOut), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(desc32, e->dDesc.p, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(kps, e->hKps.p, (size_t)n * sizeof(KeyPointOut));
+    memcpy(desc32, e->hDesc.p, (size_t)n * 32);
     return ORBFE_OK;
 }
 
