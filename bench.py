@@ -112,26 +112,26 @@ def other_configs(local_rank, dev):
     kps = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev)
     desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
     cnt = torch.zeros(2, dtype=torch.int32, device=dev)
-    bd, bi = (torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(2))
+    ur, dep = (torch.zeros(cap, dtype=torch.float32, device=dev) for _ in range(2))
     ex = capi.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
     m = capi.ORBmatcher(device=local_rank)
-    sf = ex.GetScaleFactors()
-    max_d = float(np.float32(386.1448) / np.float32(0.5371657))      # KITTI00-02.yaml: bf / b
+    bf, b = 386.1448, 0.5371657                                       # KITTI00-02.yaml: Camera.bf, bf / fx
     lat = []
     for it in range(33):
         t0 = time.perf_counter()
         ex.extract_batch_device(frames.data_ptr(), 2, W, H, stride, stride * H, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
                                 cap, sync=True)
         n = cnt.cpu().numpy()        # the matcher needs the counts on the host, as Frame::ComputeStereoMatches does
-        m.stereo_rowband_device(kps[0].data_ptr(), desc[0].data_ptr(), int(n[0]), kps[1].data_ptr(), desc[1].data_ptr(), int(n[1]),
-                                sf, H, 0.0, max_d, bd.data_ptr(), bi.data_ptr(), sync=True)
+        # Frame::ComputeStereoMatches in full: row band, SAD refinement on the device pyramids, median gate
+        m.stereo_match_device(ex, 0, ex, 1, kps[0].data_ptr(), desc[0].data_ptr(), int(n[0]), kps[1].data_ptr(),
+                              desc[1].data_ptr(), int(n[1]), bf, b, ur.data_ptr(), dep.data_ptr(), sync=True)
         if it >= 3:
             lat.append(time.perf_counter() - t0)
     out["kitti_stereo_pair_1241x376_2000kp"] = {
-        "latency_ms_pair_extract_plus_rowband": round(float(np.median(lat)) * 1e3, 4),
+        "latency_ms_pair_extract_plus_stereo_matches": round(float(np.median(lat)) * 1e3, 4),
         "pairs_per_s_sequential": round(1.0 / float(np.median(lat)), 1),
         "left_keypoints": int(n[0]), "right_keypoints": int(n[1]),
-        "rowband_matches_below_75": int((bd[:int(n[0])] < 75).sum().item())}
+        "points_with_depth": int((dep[:int(n[0])] > 0).sum().item())}
     return out
 
 

@@ -39,6 +39,10 @@ public:
     // operator() call exactly as the reference re-allocates them (src/ORBextractor.cc:1113-1115).
     std::vector<cv::Mat> mvImagePyramid;
 
+    // Not in the reference: the liborbfe handle behind this object, for the device-side stereo matcher
+    // (orbfe::StereoMatcher in ORBmatcher_orbfe.h reads the pyramids of the last call in place).
+    orbfe_extractor *orbfeHandle() const { return handle_; }
+
 protected:
     int nfeatures;
     double scaleFactor;

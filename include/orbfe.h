@@ -171,6 +171,17 @@ int orbfe_stereo_rowband(orbfe_matcher *m, const orbfe_keypoint *dev_kl, const u
                          const orbfe_keypoint *dev_kr, const uint8_t *dev_dr, int nr, const float *host_scale_factors,
                          int nlevels, int nrows, float min_d, float max_d, int32_t *dev_best_dist, int32_t *dev_best_idx,
                          int sync);
+/* replaces Frame::ComputeStereoMatches as a whole (src/Frame.cc:466-640): the row-band search above with
+ * minD = 0, maxD = mbf / mb (:496-498), then for every match below thOrbDist = 75 the 11x11 centre-subtracted SAD over
+ * +-5 px on pyramid level octL (:551-592), the parabola (:598-605), the disparity gate (:610-622) and the removal of
+ * matches whose SAD is >= 1.5*1.4*median (:626-639).  The un-blurred pyramids are read in place from the two
+ * extractors' last call (frames `left_frame` / `right_frame` of their last batch; `left` and `right` may be the same
+ * handle after a 2-frame batch); the level-0 images are the buffers that call was given and must still be alive.  The
+ * call is ordered after both extractors' streams.  Outputs mvuRight[nl], mvDepth[nl] (-1 where there is no match), on
+ * the device.  With no accepted match the reference reads past an empty vector (:627); here nothing is gated. */
+int orbfe_stereo_match(orbfe_matcher *m, orbfe_extractor *left, int left_frame, orbfe_extractor *right, int right_frame,
+                       const orbfe_keypoint *dev_kl, const uint8_t *dev_dl, int nl, const orbfe_keypoint *dev_kr,
+                       const uint8_t *dev_dr, int nr, float mbf, float mb, float *dev_uright, float *dev_depth, int sync);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

@@ -903,7 +903,7 @@ void orc_stereo_full(const orc_extractor *el, const orc_extractor *er, const orc
         float bestuR = el->mvScaleFactor[oct] * ((float)scaleduR0 + (float)bestincR + deltaR);
         float disparity = (uL - bestuR);
         if (disparity >= minD && disparity < maxD) {
-            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+            if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)uL - 0.01); }   // double literals, :616-617
             mvDepth[iL] = mbf / disparity;
             mvuRight[iL] = bestuR;
             vDistIdx.push_back(std::pair<int, int>(bestDist, iL));

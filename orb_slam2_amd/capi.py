@@ -27,7 +27,7 @@ EXPORTS = [
     "orbfe_extract", "orbfe_extract_batch", "orbfe_synchronize", "orbfe_pyramid_level", "orbfe_debug_stage",
     "orbfe_hamming", "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_match_knn2", "orbfe_match_csr",
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
-    "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode",
+    "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -85,6 +85,8 @@ def lib():
     L.orbfe_match_csr.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     L.orbfe_stereo_rowband.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float,
                                        vp, vp, C.c_int]
+    L.orbfe_stereo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp,
+                                     C.c_int]
     L.orbfe_matcher_synchronize.argtypes = [vp]
     L.orbfe_matcher_stream.restype = vp
     L.orbfe_matcher_stream.argtypes = [vp]
@@ -275,6 +277,12 @@ class ORBmatcher:
         check(self._L.orbfe_stereo_rowband(self._h, vp(kl_ptr), vp(dl_ptr), nl, vp(kr_ptr), vp(dr_ptr), nr,
                                            sf.ctypes.data_as(f32p), len(sf), nrows, min_d, max_d, vp(bd_ptr), vp(bi_ptr),
                                            1 if sync else 0))
+
+    def stereo_match_device(self, left: "ORBextractor", left_frame, right: "ORBextractor", right_frame, kl_ptr, dl_ptr, nl,
+                            kr_ptr, dr_ptr, nr, mbf, mb, uright_ptr, depth_ptr, sync=True):
+        """Frame::ComputeStereoMatches (src/Frame.cc:466-640) on the device; pyramids from the extractors' last call."""
+        check(self._L.orbfe_stereo_match(self._h, left._h, left_frame, right._h, right_frame, vp(kl_ptr), vp(dl_ptr), nl,
+                                         vp(kr_ptr), vp(dr_ptr), nr, mbf, mb, vp(uright_ptr), vp(depth_ptr), 1 if sync else 0))
 
     def synchronize(self):
         check(self._L.orbfe_matcher_synchronize(self._h))

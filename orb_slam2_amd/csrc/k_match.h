@@ -233,4 +233,154 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, int n, uint3
     if (i < n) p[i] = v;
 }
 
+// ---- stereo: SAD sub-pixel refinement and median gate (N3) ----------------------------------------------------------
+// Replaces the second half of Frame::ComputeStereoMatches (reference src/Frame.cc:551-639).  One wavefront per left
+// keypoint: lanes hold the 121 pixels of the 11x11 patch (two per lane), the eleven centre-subtracted L1 distances are
+// integer wave sums (the reference accumulates the same small integers in floating point, exactly), the parabola and
+// the disparity are float32 with individually rounded operations.  sad[iL] = best SAD of an accepted match, -1 otherwise.
+struct StereoRefineArgs {
+    const KeyPointOut *kl; int nl;
+    const KeyPointOut *kr; int nr;
+    const uint32_t *best;            // (distance << 22 | right index) from the row-band search
+    Geom g;
+    ImgSrc left, right;
+    int leftFrame, rightFrame;
+    float invScale[kMaxLevels], scale[kMaxLevels];
+    float mbf, minD, maxD;
+    float *uRight, *depth;
+    int *sad;
+};
+
+__device__ __forceinline__ int stereo_wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+__global__ __launch_bounds__(256) void stereo_refine_kernel(StereoRefineArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= a.nl) return;
+    if (lane == 0) { a.uRight[iL] = -1.0f; a.depth[iL] = -1.0f; a.sad[iL] = -1; }
+    const uint32_t bk = a.best[iL];
+    const int hd = (int)(bk >> kKeyShift), iR = (int)(bk & kKeyIdxMask);
+    if (!(hd < 75) || iR >= a.nr) return;                       // thOrbDist = (TH_HIGH + TH_LOW) / 2  (:471, :552)
+    const KeyPointOut kpL = a.kl[iL];
+    const int oct = min(max(kpL.octave, 0), a.g.nlevels - 1);
+    const float uL = kpL.x, uR0 = a.kr[iR].x;
+    const float sfi = a.invScale[oct];
+    const float scaleduL = roundf(__fmul_rn(kpL.x, sfi)), scaledvL = roundf(__fmul_rn(kpL.y, sfi)),
+                scaleduR0 = roundf(__fmul_rn(uR0, sfi));         // :557-559
+    const int w = 5, L = 5;
+    const LevelGeom &G = a.g.lv[oct];
+    const float iniu = scaleduR0 + (float)(L - w), endu = scaleduR0 + (float)(L + w + 1);
+    if (iniu < 0 || endu >= (float)G.w) return;                  // :573-576
+    const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr0 = (int)scaleduR0;
+    // the reference would throw on a window outside the level; keypoints of this library never get there
+    if (cy - w < 0 || cy + w >= G.h || cxl - w < 0 || cxl + w >= G.w || cxr0 - L - w < 0) return;
+    int pl, pr;
+    const uint8_t *imgL = level_ptr(a.left, a.g, a.leftFrame, oct, &pl);
+    const uint8_t *imgR = level_ptr(a.right, a.g, a.rightFrame, oct, &pr);
+    // patch positions p = lane and lane + 64 (< 121): (dy, dx) = (p / 11 - 5, p % 11 - 5)
+    int dy[2], dx[2], aL[2];
+    bool in[2];
+    const int cL = imgL[(size_t)cy * pl + cxl];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int p = lane + 64 * h;
+        in[h] = p < 121;
+        const int pp = in[h] ? p : 0;
+        dy[h] = pp / 11 - w;
+        dx[h] = pp - (pp / 11) * 11 - w;
+        aL[h] = (int)imgL[(size_t)(cy + dy[h]) * pl + cxl + dx[h]] - cL;
+    }
+    int bestDist = 0x7fffffff, bestincR = 0;
+    float vDists[2 * 5 + 1];
+#pragma unroll
+    for (int incR = -L; incR <= L; incR++) {
+        const int cxr = cxr0 + incR;
+        const int cR = imgR[(size_t)cy * pr + cxr];
+        int sum = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int b = (int)imgR[(size_t)(cy + dy[h]) * pr + cxr + dx[h]] - cR;
+            const int d = aL[h] - b;
+            sum += in[h] ? (d < 0 ? -d : d) : 0;
+        }
+        const float dist = (float)stereo_wave_sum(sum);          // cv::norm(IL, IR, NORM_L1)  (:584)
+        if (dist < (float)bestDist) { bestDist = (int)dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+    }
+    if (bestincR == -L || bestincR == L) return;                 // :594
+    float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+    for (int k = 1; k < 2 * 5; k++)
+        if (k == L + bestincR) { dist1 = vDists[k - 1]; dist2 = vDists[k]; dist3 = vDists[k + 1]; }
+    const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                   __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));   // :602
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = __fmul_rn(a.scale[oct], __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));            // :608
+    float disparity = __fsub_rn(uL, bestuR);
+    if (disparity >= a.minD && disparity < a.maxD) {
+        if (disparity <= 0) {
+            disparity = (float)0.01;
+            bestuR = (float)((double)uL - 0.01);                 // double expression in the reference (:616-617)
+        }
+        if (lane == 0) {
+            a.depth[iL] = __fdiv_rn(a.mbf, disparity);
+            a.uRight[iL] = bestuR;
+            a.sad[iL] = bestDist;
+        }
+    }
+}
+
+// median gate (:626-639): the accepted matches whose SAD is >= 1.5 * 1.4 * median are dropped.  median = element n/2 of
+// the ascending SADs (a SAD is < 2^16: 121 pixels x 510), found with two 256-bin histograms.  One workgroup.
+__global__ __launch_bounds__(1024) void stereo_gate_kernel(const int *__restrict__ sad, int nl, float *__restrict__ uRight,
+                                                           float *__restrict__ depth) {
+    __shared__ int hist[256];
+    __shared__ int sel[4];   // chosen high byte, rank inside it, chosen low byte, count
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 1024) {
+        const int s = sad[i];
+        if (s >= 0) atomicAdd(&hist[min(s >> 8, 255)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int b = 0; b < 256; b++) n += hist[b];
+        int k = n / 2, b = 0;
+        while (b < 255 && k >= hist[b]) { k -= hist[b]; b++; }
+        sel[0] = b; sel[1] = k; sel[3] = n;
+    }
+    __syncthreads();
+    const int n = sel[3], hb = sel[0];
+    if (n == 0) return;       // the reference indexes an empty vector here; nothing to gate
+    __syncthreads();
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 1024) {
+        const int s = sad[i];
+        if (s >= 0 && min(s >> 8, 255) == hb) atomicAdd(&hist[s & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int k = sel[1], b = 0;
+        while (b < 255 && k >= hist[b]) { k -= hist[b]; b++; }
+        sel[2] = b;
+    }
+    __syncthreads();
+    const float median = (float)((hb << 8) | sel[2]);
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = tid; i < nl; i += 1024) {
+        const int s = sad[i];
+        if (s >= 0 && !((float)s < thDist)) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    }
+}
+
 }  // namespace orbfe

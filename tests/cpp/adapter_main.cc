@@ -1,14 +1,54 @@
 // adapter_main.cc -- exercises ORB_SLAM2::ORBextractor (include/ORBextractor.h + adapters/ORBextractor_orbfe.cc) the way
 // Frame::ExtractORB does (reference src/Frame.cc:247-253), on a raw 8-bit image file, and dumps the outputs so the
 // pytest driver can compare them with the oracle.  usage: adapter_main in.raw w h nfeatures out.bin
+//                                                          adapter_main stereo left.raw right.raw w h nfeatures bf b out.bin
+// The stereo mode follows the Frame stereo constructor (src/Frame.cc:59-93): two extractors, then ComputeStereoMatches.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ORBextractor.h"
 #include "ORBmatcher_orbfe.h"
 
+static bool read_raw(const char *path, std::vector<unsigned char> &buf) {
+    FILE *fi = std::fopen(path, "rb");
+    if (!fi) return false;
+    const bool ok = std::fread(buf.data(), 1, buf.size(), fi) == buf.size();
+    std::fclose(fi);
+    return ok;
+}
+
+static int stereo_main(char **argv) {
+    const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), nf = std::atoi(argv[6]);
+    const float bf = (float)std::atof(argv[7]), b = (float)std::atof(argv[8]);
+    std::vector<unsigned char> bl((size_t)w * h), br((size_t)w * h);
+    if (!read_raw(argv[2], bl) || !read_raw(argv[3], br)) return 3;
+    cv::Mat imL(h, w, CV_8UC1, bl.data(), (size_t)w), imR(h, w, CV_8UC1, br.data(), (size_t)w);
+    ORB_SLAM2::ORBextractor exL(nf, 1.2f, 8, 20, 7), exR(nf, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> kl, kr;
+    cv::Mat dl, dr;
+    exL(imL, cv::Mat(), kl, dl);
+    exR(imR, cv::Mat(), kr, dr);
+    orbfe::StereoMatcher sm;
+    std::vector<float> uRight, depth;
+    const int rc = sm.ComputeStereoMatches(exL.orbfeHandle(), exR.orbfeHandle(), kl, dl, kr, dr, bf, b, uRight, depth);
+    if (rc != 0) { std::fprintf(stderr, "stereo: %s\n", orbfe_last_error()); return 5; }
+    FILE *fo = std::fopen(argv[9], "wb");
+    if (!fo) return 4;
+    const int n = (int)kl.size();
+    std::fwrite(&n, 4, 1, fo);
+    std::fwrite(uRight.data(), 4, n, fo);
+    std::fwrite(depth.data(), 4, n, fo);
+    std::fclose(fo);
+    int matched = 0;
+    for (float d : depth) matched += d > 0;
+    std::printf("adapter stereo ok: %d left keypoints, %d with depth\n", n, matched);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 10 && std::strcmp(argv[1], "stereo") == 0) return stereo_main(argv);
     if (argc < 6) return 2;
     const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), nf = std::atoi(argv[4]);
     std::vector<unsigned char> buf((size_t)w * h);

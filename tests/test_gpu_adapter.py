@@ -35,3 +35,29 @@ def test_cpp_adapter_matches_oracle(tmp_path):
     assert np.array_equal(lvl, np.pad(o.level(3), 19, mode="reflect"))
     d01 = int(np.frombuffer(buf, np.int32, 1, off + 8 + (pw + 38) * (ph + 38))[0])
     assert d01 == O.hamming(do[0], do[1])
+
+
+def test_cpp_stereo_matcher_matches_oracle(tmp_path):
+    """orbfe::StereoMatcher (include/ORBmatcher_orbfe.h) behind two adapter extractors == Frame::ComputeStereoMatches."""
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    assert exe.exists()
+    w, h, nf = 1241, 376, 2000
+    bf, b = 386.1448, 0.5371657
+    left, right = synth.stereo_pair(w, h, synth.BASE_SEED + 91)
+    fl, fr, out = tmp_path / "l.raw", tmp_path / "r.raw", tmp_path / "out.bin"
+    fl.write_bytes(left.tobytes())
+    fr.write_bytes(right.tobytes())
+    r = subprocess.run([str(exe), "stereo", str(fl), str(fr), str(w), str(h), str(nf), repr(bf), repr(b), str(out)],
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    n = int(np.frombuffer(buf, np.int32, 1)[0])
+    ur = np.frombuffer(buf, np.float32, n, 4)
+    dep = np.frombuffer(buf, np.float32, n, 4 + 4 * n)
+    ol, orr = O.OracleExtractor(nf, 1.2, 8, 20, 7), O.OracleExtractor(nf, 1.2, 8, 20, 7)
+    kl, dl = ol.extract(left)
+    kr, dr = orr.extract(right)
+    ref_ur, ref_dep = O.stereo_full(ol, orr, kl, dl, kr, dr, bf, b)
+    assert n == len(kl) and (ref_dep > 0).sum() > 200
+    assert np.array_equal(ur.view(np.uint32), ref_ur.view(np.uint32))
+    assert np.array_equal(dep.view(np.uint32), ref_dep.view(np.uint32))

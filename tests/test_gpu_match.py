@@ -118,3 +118,73 @@ def test_stereo_rowband_matches_oracle():
     assert np.array_equal(bd.cpu().numpy(), ref_bd)
     assert np.array_equal(bi.cpu().numpy(), ref_bi)
     assert (ref_bd < 75).sum() > 200                 # the synthetic pair really produces stereo matches
+
+
+@pytest.mark.parametrize("same_handle", [False, True])
+def test_stereo_match_full_matches_oracle(same_handle):
+    """N3: row band + 11x11 SAD refinement + parabola + median gate (src/Frame.cc:466-640); mvuRight / mvDepth bit-exact."""
+    W, H = 1241, 376
+    left, right = synth.stereo_pair(W, H, synth.BASE_SEED + 77)
+    ol, orr = O.OracleExtractor(2000, 1.2, 8, 20, 7), O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    kol, dol = ol.extract(left)
+    kor, dor = orr.extract(right)
+    bf, b = 386.1448, 0.5371657                      # KITTI00-02.yaml: Camera.bf, bf / fx(718.856)
+    ref_ur, ref_dep = O.stereo_full(ol, orr, kol, dol, kor, dor, bf, b)
+    assert (ref_dep > 0).sum() > 200                 # the pair produces real stereo matches, and the gate removes some
+    m = capi.ORBmatcher()
+    stride = (W + 63) // 64 * 64
+    cap = 2100
+    if same_handle:
+        host = np.zeros((2, H, stride), np.uint8)
+        host[0, :, :W], host[1, :, :W] = left, right
+        frames = torch.from_numpy(host).cuda()
+        ex = capi.ORBextractor(2000, 1.2, 8, 20, 7)
+        kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(frames.data_ptr(), 2, W, H, stride, stride * H, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
+                                cap, sync=False)    # the matcher must order itself after the extractor's stream
+        nl, nr = len(kol), len(kor)
+        ur = torch.zeros(nl, dtype=torch.float32, device="cuda")
+        dep = torch.zeros(nl, dtype=torch.float32, device="cuda")
+        m.stereo_match_device(ex, 0, ex, 1, kps[0].data_ptr(), desc[0].data_ptr(), nl, kps[1].data_ptr(), desc[1].data_ptr(), nr,
+                              bf, b, ur.data_ptr(), dep.data_ptr())
+        n = cnt.cpu().numpy()
+        assert n[0] == nl and n[1] == nr
+    else:
+        gl, gr = capi.ORBextractor(2000, 1.2, 8, 20, 7), capi.ORBextractor(2000, 1.2, 8, 20, 7)
+        kl, dl = gl(left)
+        kr, dr = gr(right)
+        assert np.array_equal(kl, kol) and np.array_equal(dr, dor)
+        dkl = _dev(kl.view(np.uint8).reshape(-1, 28))
+        dkr = _dev(kr.view(np.uint8).reshape(-1, 28))
+        ddl, ddr = _dev(dl), _dev(dr)
+        ur = torch.zeros(len(kl), dtype=torch.float32, device="cuda")
+        dep = torch.zeros(len(kl), dtype=torch.float32, device="cuda")
+        m.stereo_match_device(gl, 0, gr, 0, dkl.data_ptr(), ddl.data_ptr(), len(kl), dkr.data_ptr(), ddr.data_ptr(), len(kr),
+                              bf, b, ur.data_ptr(), dep.data_ptr())
+    got_ur, got_dep = ur.cpu().numpy(), dep.cpu().numpy()
+    assert np.array_equal(got_ur.view(np.uint32), ref_ur.view(np.uint32))      # bit-exact float32
+    assert np.array_equal(got_dep.view(np.uint32), ref_dep.view(np.uint32))
+
+
+def test_stereo_match_no_matches_and_argument_errors():
+    W, H = 640, 480
+    img = synth.textured_image(W, H, synth.BASE_SEED + 5)
+    g = capi.ORBextractor(500, 1.2, 8, 20, 7)
+    k, d = g(img)
+    m = capi.ORBmatcher()
+    dk, dd = _dev(k.view(np.uint8).reshape(-1, 28)), _dev(d)
+    ur = torch.full((len(k),), 7.0, dtype=torch.float32, device="cuda")
+    dep = torch.full((len(k),), 7.0, dtype=torch.float32, device="cuda")
+    # no right keypoints: every entry is -1, the gate has nothing to do
+    m.stereo_match_device(g, 0, g, 0, dk.data_ptr(), dd.data_ptr(), len(k), dk.data_ptr(), dd.data_ptr(), 0, 40.0, 0.08,
+                          ur.data_ptr(), dep.data_ptr())
+    assert (ur.cpu().numpy() == -1).all() and (dep.cpu().numpy() == -1).all()
+    with pytest.raises(capi.OrbfeError):
+        m.stereo_match_device(g, 1, g, 0, dk.data_ptr(), dd.data_ptr(), len(k), dk.data_ptr(), dd.data_ptr(), len(k), 40.0, 0.08,
+                              ur.data_ptr(), dep.data_ptr())
+    fresh = capi.ORBextractor(500, 1.2, 8, 20, 7)
+    with pytest.raises(capi.OrbfeError):
+        m.stereo_match_device(g, 0, fresh, 0, dk.data_ptr(), dd.data_ptr(), len(k), dk.data_ptr(), dd.data_ptr(), len(k), 40.0,
+                              0.08, ur.data_ptr(), dep.data_ptr())

@@ -441,3 +441,77 @@ def test_extract_end_to_end_invariants(kitti_frame):
     # empty image: outputs untouched / zero keypoints
     k0, d0 = O.OracleExtractor().extract(np.zeros((376, 1241), np.uint8))
     assert len(k0) == 0
+
+
+def _stereo_full_numpy(ol, orr, kl, dl, kr, dr, bf, b):
+    """Independent restatement of Frame::ComputeStereoMatches after the row-band search (src/Frame.cc:551-639)."""
+    f32 = np.float32
+    nl = len(kl)
+    ur, dep = np.full(nl, -1, f32), np.full(nl, -1, f32)
+    sf, isf = ol.tables()["scale"], ol.tables()["inv_scale"]
+    maxD = f32(bf) / f32(b)
+    bd, bi = O.stereo_rowband(kl, dl, kr, dr, sf, ol.level(0).shape[0], 0.0, float(maxD))
+    LV = [ol.level(l).astype(np.int64) for l in range(ol.nlevels)]
+    RV = [orr.level(l).astype(np.int64) for l in range(ol.nlevels)]
+    acc = []
+    rnd = lambda v: f32(np.floor(abs(float(v)) + 0.5) * (1 if v >= 0 else -1))   # C round(): halves away from zero
+    for iL in range(nl):
+        if not bd[iL] < 75:
+            continue
+        o = int(kl["octave"][iL])
+        uL, uR0 = f32(kl["x"][iL]), f32(kr["x"][bi[iL]])
+        suL, svL, suR0 = rnd(uL * isf[o]), rnd(f32(kl["y"][iL]) * isf[o]), rnd(uR0 * isf[o])
+        PL, PR = LV[o], RV[o]
+        if suR0 < 0 or suR0 + 11 >= PR.shape[1]:
+            continue
+        cy, cxl, cxr0 = int(svL), int(suL), int(suR0)
+        IL = PL[cy - 5:cy + 6, cxl - 5:cxl + 6] - PL[cy, cxl]
+        dists = []
+        for inc in range(-5, 6):
+            cx = cxr0 + inc
+            IR = PR[cy - 5:cy + 6, cx - 5:cx + 6] - PR[cy, cx]
+            dists.append(f32(np.abs(IL - IR).sum()))
+        best = int(np.argmin(dists))               # first minimum: strict '<' in ascending incR
+        if best == 0 or best == 10:
+            continue
+        d1, d2, d3 = dists[best - 1], dists[best], dists[best + 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = f32(d1 - d3) / f32(f32(2) * f32(f32(d1 + d3) - f32(f32(2) * d2)))
+        if delta < -1 or delta > 1:
+            continue
+        buR = f32(sf[o] * f32(f32(suR0 + f32(best - 5)) + delta))
+        disp = f32(uL - buR)
+        if disp >= 0 and disp < maxD:
+            if disp <= 0:
+                disp = f32(0.01)
+                buR = f32(float(uL) - 0.01)
+            dep[iL] = f32(bf) / disp
+            ur[iL] = buR
+            acc.append((int(dists[best]), iL))
+    if acc:
+        acc.sort()
+        th = f32(f32(1.5) * f32(1.4)) * f32(acc[len(acc) // 2][0])
+        for d, i in acc:
+            if not f32(d) < th:
+                ur[i] = dep[i] = -1
+    return ur, dep, len(acc)
+
+
+def test_stereo_full_vs_numpy_and_geometry():
+    W, H = 752, 480
+    left, right = synth.stereo_pair(W, H, synth.BASE_SEED + 31)
+    ol, orr = O.OracleExtractor(1000, 1.2, 8, 20, 7), O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    kl, dl = ol.extract(left)
+    kr, dr = orr.extract(right)
+    bf, b = 47.90639384423901, 0.110074            # EuRoC.yaml: Camera.bf, baseline
+    ur, dep = O.stereo_full(ol, orr, kl, dl, kr, dr, bf, b)
+    nur, ndep, accepted = _stereo_full_numpy(ol, orr, kl, dl, kr, dr, bf, b)
+    assert np.array_equal(ur.view(np.uint32), nur.view(np.uint32))
+    assert np.array_equal(dep.view(np.uint32), ndep.view(np.uint32))
+    ok = dep > 0
+    assert ok.sum() > 100 and accepted > ok.sum()       # matches exist, and the median gate removed some of them
+    # geometry: depth = bf / disparity, right coordinate left of the left one, disparity inside the synthetic range [2, 60] +- 1
+    disp = kl["x"][ok] - ur[ok]
+    assert np.allclose(dep[ok], np.float32(bf) / disp, rtol=1e-6)
+    assert (disp > 0).all() and (disp < 62 * 1.2 ** 7).all()
+    assert np.all((ur == -1) == (dep == -1))
