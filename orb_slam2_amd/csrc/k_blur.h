@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
     const uint32_t selE = isRightEdge ? kSelE[r] : 0x03020100u, selO = isRightEdge ? kSelO[r] : 0x03020100u;
     const uint32_t selER = kSelER[r], selOR = kSelOR[r];
     const uint32_t xl = (uint32_t)min(max(x0, 0), pitch - 4);
+    const bool hasEdge = __ballot(isLeftEdge || isRightEdge) != 0;
 
     uint32_t E[7], O[7];
 #pragma unroll
@@ -122,12 +123,20 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
                 vo += (bpk(O[s2]) + bpk(O[s4])) * k49;
                 const uint32_t VE0 = bu32(ve), VO0 = bu32(vo);
                 uint32_t VEL = dpp_lane_m1(VE0), VOL = dpp_lane_m1(VO0);
-                VOL = isLeftEdge ? __builtin_amdgcn_alignbit(VO0, VO0, 16) : VOL;
-                VEL = isLeftEdge ? VE0 : VEL;
-                const uint32_t VE = __builtin_amdgcn_perm(VEL, VE0, selE), VO = __builtin_amdgcn_perm(VOL, VO0, selO);
-                uint32_t VER = dpp_lane_p1(VE), VOR = dpp_lane_p1(VO);
-                VER = isRightEdge ? __builtin_amdgcn_perm(VEL, VE0, selER) : VER;
-                VOR = isRightEdge ? __builtin_amdgcn_perm(VOL, VO0, selOR) : VOR;
+                uint32_t VE = VE0, VO = VO0, VER, VOR;
+                if (hasEdge) {   // wave-uniform: only the first and the last strip of a level hold an image edge
+                    VOL = isLeftEdge ? __builtin_amdgcn_alignbit(VO0, VO0, 16) : VOL;
+                    VEL = isLeftEdge ? VE0 : VEL;
+                    VE = __builtin_amdgcn_perm(VEL, VE0, selE);
+                    VO = __builtin_amdgcn_perm(VOL, VO0, selO);
+                    VER = dpp_lane_p1(VE);
+                    VOR = dpp_lane_p1(VO);
+                    VER = isRightEdge ? __builtin_amdgcn_perm(VEL, VE0, selER) : VER;
+                    VOR = isRightEdge ? __builtin_amdgcn_perm(VOL, VO0, selOR) : VOR;
+                } else {
+                    VER = dpp_lane_p1(VE0);
+                    VOR = dpp_lane_p1(VO0);
+                }
                 // row pass: out_j = sum_i k[i] * V[j+i-3] + 32768
                 uint32_t o0 = bdot2(VOL, bw(18, 49), 32768u);
                 o0 = bdot2(VEL, bw(0, 34), o0);

@@ -32,9 +32,21 @@
 
 namespace orbfe {
 
-constexpr int kFastStripMaxDw = 62;   // detection lanes 1..62; lanes 0 and 63 are halo
+constexpr int kFastStripMaxDw = 62;   // detection lanes of a segment that fills a wave; one halo lane on each side
+constexpr int kFastMaxSeg = 6;        // segments (pieces of different cell rows of one level) packed into one wavefront
+constexpr int kFastMaxCells = 8;      // cells per wavefront, over all its segments
 
-struct FastTile { uint16_t level, strip, cellRow, pad; };
+// A segment is nCells whole cells [c0, c0 + nCells) of cell row `cellRow`; it occupies nLanes consecutive lanes from
+// lane0: a left halo lane, ceil(pixels / 4) detection lanes, a right halo lane.  Strips that do not fill a wave (the
+// remainder of a cell row) are packed together, so that narrow levels do not leave most of a wavefront idle.  All
+// segments of a tile belong to one level and have the same number of rows.
+struct FastSeg { uint16_t cellRow, c0; uint8_t nCells, lane0, nLanes, pad; };
+struct FastTile {
+    uint16_t level, nSeg;
+    uint16_t pad[2];
+    FastSeg seg[kFastMaxSeg];
+};
+static_assert(sizeof(FastTile) == 56, "FastTile");
 
 constexpr int kFastListCap = 1024;    // survivor records (one per lane and row) a wave can hold for its strip (dense texture: ~150)
 
@@ -117,29 +129,42 @@ __device__ __forceinline__ void fast_row_pairs(uint32_t raw, uint32_t (&q)[8]) {
 
 __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     __shared__ uint2 sList[4][kFastListCap];
-    __shared__ int sCellMax[4][8];
+    __shared__ int sCellMax[4][kFastMaxCells];
+    __shared__ int4 sSeg[4][kFastMaxSeg];   // per segment: first lane, first cell (in wave), x and y of its origin in the output
     const int lane = threadIdx.x & 63;
     const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ti >= a.nTiles) return;
-    const FastTile t = a.tiles[ti];
+    const FastTile &t = a.tiles[ti];
     const int f = blockIdx.y;
-    const LevelGeom &L = a.g.lv[t.level];
+    const int level = t.level, nSeg = t.nSeg;
+    const LevelGeom &L = a.g.lv[level];
     const int w = L.w, h = L.h;
-    const int Y0 = kEdge + t.cellRow * L.hCell;
-    const int dh = min(Y0 + L.hCell, h - kEdge) - Y0;
-    if (dh <= 0) return;
-    int pitch;
-    const uint8_t *img = level_ptr(a.s, a.g, f, t.level, &pitch);
-    // strip = cells [c0, c1) of this cell row; lane 2 holds the dword with the strip's first detection pixel
     const int wvi = threadIdx.x >> 6;
-    const int c0 = t.strip * L.fastCellsPerStrip, c1 = min(c0 + L.fastCellsPerStrip, L.nCols);
-    const int Xs = kEdge + c0 * L.wCell, Xe = min(kEdge + c1 * L.wCell, w - kEdge);
-    if (Xe <= Xs) return;
-    // The wave's 64 dwords start at pixel Xs-4 whatever its alignment (unaligned dword loads): lane 0 is the left halo,
-    // lanes 1..62 hold up to 248 detection pixels (8 cells of 31), lane 63 the right halo.
-    const int x0 = Xs - 4 + 4 * lane;            // >= 15
-    const int xl = min(x0, pitch - 4);           // lanes past the row: a legal address, value unused (needed pixels are < w-16)
-    uint32_t ownMask = 0;                        // per byte: is the pixel a detection pixel of this strip
+    int pitch;
+    const uint8_t *img = level_ptr(a.s, a.g, f, level, &pitch);
+    // the lane's segment.  Its 4 pixels start at x0 = Xs - 4 + 4 * (lane - lane0) whatever the alignment (unaligned dword
+    // loads): lane0 is the left halo, then the detection lanes, then the right halo.  Lanes outside every segment idle.
+    int Xs = kEdge, Xe = kEdge, Y0 = kEdge, segLane0 = 0, nCellsTotal = 0;
+    bool inSeg = false;
+    for (int sgi = 0; sgi < nSeg; sgi++) {   // wave-uniform trip count
+        const FastSeg sg = t.seg[sgi];
+        const int sXs = kEdge + sg.c0 * L.wCell, sXe = min(kEdge + (sg.c0 + sg.nCells) * L.wCell, w - kEdge);
+        const bool mine = lane >= sg.lane0 && lane < sg.lane0 + sg.nLanes;
+        if (mine || sgi == 0) {              // lanes of no segment read segment 0's rows (legal addresses) and own nothing
+            Xs = sXs; Y0 = kEdge + sg.cellRow * L.hCell; segLane0 = sg.lane0;
+            Xe = mine ? sXe : sXs;
+        }
+        inSeg = inSeg || mine;
+        if (lane == sgi) sSeg[wvi][sgi] = make_int4(sg.lane0, nCellsTotal, 3 + sg.c0 * L.wCell, 3 + sg.cellRow * L.hCell);
+        nCellsTotal += sg.nCells;
+    }
+    const int dh = min(kEdge + t.seg[0].cellRow * L.hCell + L.hCell, h - kEdge) - (kEdge + t.seg[0].cellRow * L.hCell);   // same for all segments
+    if (dh <= 0) return;
+    const int x0 = Xs - 4 + 4 * (lane - segLane0);
+    // lanes past the row (or left of it, for idle lanes): a legal address, value unused (needed pixels are in [16, w-16))
+    const int xl = min(max(x0, 0), pitch - 4);
+    const uint32_t rowOff = (uint32_t)((Y0 - 3) * pitch + xl);
+    uint32_t ownMask = 0;                        // per byte: is the pixel a detection pixel of this lane's segment
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const int x = x0 + b;
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     // prologue: rows Y0-3 .. Y0+2 into window slots 0..5 (16 <= row <= h-17: always inside the image)
 #pragma unroll
     for (int u = 0; u < 6; u++)
-        fast_row_pairs(*reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 - 3 + u) * pitch + xl), Q[u]);
+        fast_row_pairs(*reinterpret_cast<const uint32_t *>(img + (size_t)u * pitch + rowOff), Q[u]);
 #pragma unroll
     for (int k = 0; k < 8; k++) Q[6][k] = 0;
     FastRowS cur, prev;                 // score rows c (newest) and c-1
@@ -193,7 +218,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
             const int c = cb + u7;
             if (c >= dh) break;
             const int u = (6 + u7) % 7;   // slot of the newest row
-            fast_row_pairs(*reinterpret_cast<const uint32_t *>(img + (size_t)(Y0 + 3 + c) * pitch + xl), Q[u]);
+            fast_row_pairs(*reinterpret_cast<const uint32_t *>(img + (size_t)(6 + c) * pitch + rowOff), Q[u]);
             // window slots: row c-3 = (u+1)%7 ... row c = (u+4)%7 ... row c+3 = u
             const int s0 = (u + 1) % 7, s1 = (u + 2) % 7, s2 = (u + 3) % 7, s3 = (u + 4) % 7, s4 = (u + 5) % 7,
                       s5 = (u + 6) % 7, s6 = u;
@@ -252,15 +277,20 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
         if (lane == 0) atomicOr(a.status, 4);
         listCount = kFastListCap;
     }
-    const int nCells = c1 - c0;                      // <= 8
+    // a record's lane gives its segment (sSeg), the segment gives the cell numbering and the output origin
+    auto rec_seg = [&](uint32_t recLane) {
+        int si = 0;
+        for (int k = 1; k < nSeg; k++) si += (int)recLane >= sSeg[wvi][k].x ? 1 : 0;   // segments are in lane order
+        return sSeg[wvi][si];
+    };
     const int wCell = L.wCell;
-    const int relLane0 = -4;                         // x - Xs of byte 0 of lane 0
     // pass A: cell maxima
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         if (i < listCount) {
             const uint2 rec = sList[wvi][i];
-            const int rel0 = relLane0 + 4 * (int)(rec.y & 63);
+            const int4 sg = rec_seg(rec.y & 63);
+            const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;   // x - Xs of byte 0
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int sv = (rec.x >> (8 * b)) & 0xFF;
@@ -268,66 +298,86 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
                     const int rel = rel0 + b;
                     int cis = 0;
 #pragma unroll
-                    for (int c = 1; c < 8; c++) cis += rel >= c * wCell ? 1 : 0;
-                    atomicMax(&sCellMax[wvi][cis], sv);
+                    for (int c = 1; c < kFastMaxCells; c++) cis += rel >= c * wCell ? 1 : 0;
+                    atomicMax(&sCellMax[wvi][min(sg.y + cis, kFastMaxCells - 1)], sv);
                 }
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int thCell[8], cntCell[8];
+    int thCell[kFastMaxCells], cntCell[kFastMaxCells];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        thCell[c] = (c < nCells && sCellMax[wvi][c] > a.iniTh) ? a.iniTh : a.minTh;
+    for (int c = 0; c < kFastMaxCells; c++) {
+        thCell[c] = (c < nCellsTotal && sCellMax[wvi][c] > a.iniTh) ? a.iniTh : a.minTh;
         cntCell[c] = 0;
     }
+    // the wave-cell (0..7, -1 if the byte holds no survivor) of the four bytes of a record
+    auto rec_cells = [&](const uint2 &rec, const int4 &sg, int (&cw)[4]) {
+        const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int sv = (rec.x >> (8 * b)) & 0xFF, rel = rel0 + b;
+            int cis = 0;
+#pragma unroll
+            for (int c = 1; c < kFastMaxCells; c++) cis += rel >= c * wCell ? 1 : 0;
+            cw[b] = sv ? min(sg.y + cis, kFastMaxCells - 1) : -1;
+        }
+    };
     // pass B: candidates per cell.  Two bytes of one dword can both be kept (never adjacent ones), possibly in two cells.
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
-        const int rel0 = relLane0 + 4 * (int)(rec.y & 63);
+        const int4 sg = rec_seg(rec.y & 63);
+        int cw[4];
+        rec_cells(rec, sg, cw);
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < kFastMaxCells; c++) {
             int n = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int sv = (rec.x >> (8 * b)) & 0xFF, rel = rel0 + b;
-                n += (sv > thCell[c] && rel >= c * wCell && rel < (c + 1) * wCell) ? 1 : 0;
-            }
+            for (int b = 0; b < 4; b++) n += (cw[b] == c && (int)((rec.x >> (8 * b)) & 0xFF) > thCell[c]) ? 1 : 0;
             cntCell[c] += __popcll(__ballot(n >= 1)) + __popcll(__ballot(n >= 2));
         }
     }
-    int offCell[8], total = 0;
+    int offCell[kFastMaxCells], total = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) { offCell[c] = total; total += cntCell[c]; }
+    for (int c = 0; c < kFastMaxCells; c++) { offCell[c] = total; total += cntCell[c]; }
     int base = 0;
-    if (lane == 0 && total) base = atomicAdd(&a.levelCount[f * kMaxLevels + t.level], total);
+    if (lane == 0 && total) base = atomicAdd(&a.levelCount[f * kMaxLevels + level], total);
     base = __shfl(base, 0);
     {
-        int2 *tab = a.cellTab + (size_t)f * a.g.totalCells + L.cellBase + t.cellRow * L.nCols + c0;
+        // lane c writes the table entry of wave-cell c: find its segment, then (cell row, cell column)
+        int tabIdx = -1;
+        int cellsBefore = 0;
+        for (int sgi = 0; sgi < nSeg; sgi++) {
+            const FastSeg sg = t.seg[sgi];
+            if (lane >= cellsBefore && lane < cellsBefore + sg.nCells) tabIdx = sg.cellRow * L.nCols + sg.c0 + (lane - cellsBefore);
+            cellsBefore += sg.nCells;
+        }
+        int2 *tab = a.cellTab + (size_t)f * a.g.totalCells + L.cellBase;
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            if (lane == c && c < nCells) tab[c] = make_int2(base + offCell[c], cntCell[c]);
+        for (int c = 0; c < kFastMaxCells; c++)
+            if (lane == c && tabIdx >= 0) tab[tabIdx] = make_int2(base + offCell[c], cntCell[c]);
     }
     Cand *out = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
-    int run[8];
+    int run[kFastMaxCells];
 #pragma unroll
-    for (int c = 0; c < 8; c++) run[c] = base + offCell[c];
+    for (int c = 0; c < kFastMaxCells; c++) run[c] = base + offCell[c];
     // pass C: write, records ascending then bytes ascending inside each cell (= cv::FAST's row-major order)
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
-        const int rel0 = relLane0 + 4 * (int)(rec.y & 63);
+        const int4 sg = rec_seg(rec.y & 63);
+        int cw[4];
+        rec_cells(rec, sg, cw);
         int pos[4] = {-1, -1, -1, -1};
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < kFastMaxCells; c++) {
             int n = 0;
             bool in[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const int sv = (rec.x >> (8 * b)) & 0xFF, rel = rel0 + b;
-                in[b] = sv > thCell[c] && rel >= c * wCell && rel < (c + 1) * wCell;
+                in[b] = cw[b] == c && (int)((rec.x >> (8 * b)) & 0xFF) > thCell[c];
                 n += in[b] ? 1 : 0;
             }
             const unsigned long long B1 = __ballot(n >= 1), B2 = __ballot(n >= 2);
@@ -338,13 +388,14 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
                 if (in[b]) pos[b] = before++;
             run[c] += __popcll(B1) + __popcll(B2);
         }
+        const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             if (pos[b] >= 0 && pos[b] < L.candCap) {
                 // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
                 Cand cnd;
-                cnd.x = (uint16_t)(rel0 + b + 3 + c0 * wCell);
-                cnd.y = (uint16_t)((rec.y >> 8) + 3 + t.cellRow * L.hCell);
+                cnd.x = (uint16_t)(rel0 + b + sg.z);
+                cnd.y = (uint16_t)((rec.y >> 8) + sg.w);
                 cnd.resp = (uint16_t)(((rec.x >> (8 * b)) & 0xFF) - 1);
                 cnd.pad = 0;
                 out[pos[b]] = cnd;

@@ -253,18 +253,50 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
         if (L.wCell > 64 || L.hCell > 64)   // cannot happen for 30-px cells (wCell < 60), kept as a guard for the select kernel
             return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell wider than a wavefront");
         {
-            // FAST strips: whole cells per wavefront, at most 8 cells and 62 dword columns (+ 1 halo lane each side)
-            L.fastCellsPerStrip = std::max(1, std::min(8, (4 * kFastStripMaxDw) / L.wCell));
-            const int nStrips = (L.nCols + L.fastCellsPerStrip - 1) / L.fastCellsPerStrip;
+            // FAST tiles: a wavefront takes whole cells, at most 8 of them and 62 dword columns (+ 1 halo lane each side).
+            // Full strips get a wave each; the remainder strips of cell rows with the same height are packed together.
+            L.fastCellsPerStrip = std::max(1, std::min(kFastMaxCells, (4 * kFastStripMaxDw) / L.wCell));
+            auto seg_lanes = [&](int c0, int n) {
+                const int xs = kEdge + c0 * L.wCell, xe = std::min(kEdge + (c0 + n) * L.wCell, L.w - kEdge);
+                return (xe - xs + 3) / 4 + 2;
+            };
+            FastTile open{};           // the tile collecting remainder segments
+            int openLanes = 0, openCells = 0, openDh = -1;
+            auto flush_open = [&]() {
+                if (open.nSeg) e->hFastTiles.push_back(open);
+                open = FastTile{};
+                openLanes = openCells = 0;
+                openDh = -1;
+            };
             for (int i = 0; i < L.nRows; i++) {
-                if (kEdge + i * L.hCell >= L.h - kEdge) continue;
-                for (int sidx = 0; sidx < nStrips; sidx++) {
-                    if (kEdge + sidx * L.fastCellsPerStrip * L.wCell >= L.w - kEdge) continue;
-                    FastTile t;
-                    t.level = (uint16_t)l; t.strip = (uint16_t)sidx; t.cellRow = (uint16_t)i; t.pad = 0;
-                    e->hFastTiles.push_back(t);
+                const int y0 = kEdge + i * L.hCell;
+                if (y0 >= L.h - kEdge) continue;
+                const int dh = std::min(y0 + L.hCell, L.h - kEdge) - y0;
+                for (int c0 = 0; c0 < L.nCols; c0 += L.fastCellsPerStrip) {
+                    if (kEdge + c0 * L.wCell >= L.w - kEdge) continue;
+                    const int n = std::min(L.fastCellsPerStrip, L.nCols - c0);
+                    const int lanes = seg_lanes(c0, n);
+                    FastSeg sg{};
+                    sg.cellRow = (uint16_t)i; sg.c0 = (uint16_t)c0; sg.nCells = (uint8_t)n; sg.nLanes = (uint8_t)lanes;
+                    if (n == L.fastCellsPerStrip || lanes > 32) {   // nothing else of this level fits beside it
+                        FastTile t{};
+                        t.level = (uint16_t)l; t.nSeg = 1;
+                        t.seg[0] = sg;
+                        e->hFastTiles.push_back(t);
+                        continue;
+                    }
+                    if (open.nSeg && (dh != openDh || openLanes + lanes > 64 || openCells + n > kFastMaxCells ||
+                                      open.nSeg == kFastMaxSeg))
+                        flush_open();
+                    sg.lane0 = (uint8_t)openLanes;
+                    open.level = (uint16_t)l;
+                    open.seg[open.nSeg++] = sg;
+                    openLanes += lanes;
+                    openCells += n;
+                    openDh = dh;
                 }
             }
+            flush_open();
         }
         L.cellBase = cellBase;
         cellBase += L.nCols * L.nRows;
