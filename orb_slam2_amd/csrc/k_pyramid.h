@@ -38,9 +38,13 @@ struct ResizeArgs {
 };
 
 struct __attribute__((packed, aligned(1))) RszWindow { uint32_t lo, hi; };
+struct __attribute__((packed, aligned(1))) RszWindow3 { uint32_t lo, hi, top; };
 
 typedef uint16_t rsz_u16x2 __attribute__((ext_vector_type(2)));
 
+// WIDE = false: the lane's four pixel pairs lie inside 8 bytes (scale factors up to ~1.99).  WIDE = true: 12-byte window,
+// the fourth pixel reads a view shifted by 3 bytes (two v_alignbyte_b32 per source row), good up to scale factors of 3.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -54,11 +58,12 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
     const uint4 t01 = *reinterpret_cast<const uint4 *>(a.xtab + x0), t23 = *reinterpret_cast<const uint4 *>(a.xtab + x0 + 2);
     const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
     const uint32_t coef[4] = {t01.y, t01.w, t23.y, t23.w};
-    const int base = min(ofs[0], a.sPitch - 8);   // the 8-byte window never leaves the row's pitch
+    const int base = min(ofs[0], a.sPitch - (WIDE ? 12 : 8));   // the window never leaves the row's pitch
     uint32_t sel[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int o0 = ofs[i] - base, o1 = min(ofs[i] + 1, a.sw - 1) - base;   // when sx == sw-1 the right weight is 0
+        const int view = (WIDE && i == 3) ? 3 : 0;   // pixel 3 of a wide window selects from bytes 3..10
+        const int o0 = ofs[i] - base - view, o1 = min(ofs[i] + 1, a.sw - 1) - base - view;   // sx == sw-1: right weight is 0
         sel[i] = (uint32_t)o0 | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;
     }
     // ---- the row block's row-table entries, one per lane, and its source rows
@@ -66,10 +71,17 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
     const int ylOfs = ytl.ofs, ylCoef = ytl.coef;
     const int sy0 = min(max(__builtin_amdgcn_readfirstlane(ylOfs), 0), a.sh - 1);
     const uint8_t *srcF = a.src + (size_t)f * a.sFrameStride + base;
-    RszWindow raw[kRszSrcRows];
+    RszWindow3 raw[kRszSrcRows];
 #pragma unroll
-    for (int j = 0; j < kRszSrcRows; j++)
-        raw[j] = *reinterpret_cast<const RszWindow *>(srcF + (size_t)min(sy0 + j, a.sh - 1) * a.sPitch);
+    for (int j = 0; j < kRszSrcRows; j++) {
+        const uint8_t *rp = srcF + (size_t)min(sy0 + j, a.sh - 1) * a.sPitch;
+        if (WIDE) {
+            raw[j] = *reinterpret_cast<const RszWindow3 *>(rp);
+        } else {
+            const RszWindow v = *reinterpret_cast<const RszWindow *>(rp);
+            raw[j].lo = v.lo; raw[j].hi = v.hi; raw[j].top = 0;
+        }
+    }
 
     uint8_t *dstF = a.dst + (size_t)f * a.dFrameStride + x0;
     const bool writer = x0 < a.dw;   // dPitch is a multiple of 64 >= round_up(dw, 4): the dword store stays inside the row
@@ -80,7 +92,12 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Hp[i] = Hc[i];
-            const uint32_t pr = __builtin_amdgcn_perm(raw[j].hi, raw[j].lo, sel[i]);
+            uint32_t lo = raw[j].lo, hi = raw[j].hi;
+            if (WIDE && i == 3) {
+                lo = __builtin_amdgcn_alignbyte(raw[j].hi, raw[j].lo, 3);
+                hi = __builtin_amdgcn_alignbyte(raw[j].top, raw[j].hi, 3);
+            }
+            const uint32_t pr = __builtin_amdgcn_perm(hi, lo, sel[i]);
             Hc[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rsz_u16x2, pr), __builtin_bit_cast(rsz_u16x2, coef[i]), 0u, false) >> 4;
         }
         while (dy < y1) {

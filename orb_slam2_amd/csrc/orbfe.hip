@@ -110,6 +110,7 @@ struct orbfe_extractor {
     bool haveGeom = false;
     std::vector<RszTab> hRsz;           // all levels' x and y tables
     std::vector<int> rszRows;           // output rows per wavefront of the resize kernel, per level
+    std::vector<char> rszWide;          // level needs the 12-byte source window (scale factor ~2 and above)
     std::vector<BlurTile> hBlurTiles;
     std::vector<FastTile> hFastTiles;
     DevBuf dRsz, dBlurTiles, dFastTiles;
@@ -228,6 +229,7 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
     e->hBlurTiles.clear();
     e->hFastTiles.clear();
     e->rszRows.assign(nl, 1);
+    e->rszWide.assign(nl, 0);
     int pyrOff = 0, blurOff = 0, cellBase = 0, candOff = 0, selOff = 0;
     for (int l = 0; l < nl; l++) {
         LevelGeom &L = g.lv[l];
@@ -333,14 +335,21 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
                 }
                 if (ok) rows = r;
             }
-            // the lane's 4 source pixel pairs must lie inside its 8-byte window (true for scale factors in (1, 2])
-            bool fits = rows > 0 && P.w >= 8;
-            for (int x0 = 0; x0 < L.w && fits; x0 += 4) {
-                const int last = std::min(x0 + 3, L.w - 1);
-                fits = std::min(xt[last].ofs + 1, P.w - 1) - std::min(xt[x0].ofs, round_up(P.w, 16) - 8) <= 7 &&
-                       xt[last].ofs >= xt[x0].ofs;
+            // the lane's 4 source pixel pairs must lie inside its 8-byte window (scale factors below ~2) or, with the wide
+            // variant of the kernel, pixels 0..2 inside 8 bytes and pixel 3 inside bytes 3..10 of a 12-byte window
+            bool narrow = rows > 0 && P.w >= 12, wide = narrow;
+            for (int x0 = 0; x0 < L.w && wide; x0 += 4) {
+                const int l2 = std::min(x0 + 2, L.w - 1), l3 = std::min(x0 + 3, L.w - 1);
+                const int end3 = std::min(xt[l3].ofs + 1, P.w - 1), end2 = std::min(xt[l2].ofs + 1, P.w - 1);
+                const int b8 = std::min(xt[x0].ofs, round_up(P.w, 16) - 8), b12 = std::min(xt[x0].ofs, round_up(P.w, 16) - 12);
+                if (xt[l3].ofs < xt[x0].ofs) wide = narrow = false;
+                if (end3 - b8 > 7) narrow = false;
+                // (pixel 3 past the last column is a padded table entry whose result lands in the row padding)
+                if (end2 - b12 > 7 || end3 - b12 > 10 || (x0 + 3 < L.w && xt[l3].ofs - b12 < 3)) wide = false;
             }
-            if (!fits) return fail(ORBFE_ERR_UNSUPPORTED, "scale factor outside the resize kernel's window (1 < scale <= 2)");
+            if (!narrow && !wide)
+                return fail(ORBFE_ERR_UNSUPPORTED, "scale factor outside the resize kernel's window (1 < scale < 3)");
+            e->rszWide[l] = !narrow;
             e->rszRows[l] = rows;
         }
         for (int ty = 0; ty * kBlurRows < L.h; ty++)
@@ -573,7 +582,10 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.nStrips = (L.w + kRszStripPx - 1) / kRszStripPx;
         a.rows = e->rszRows[l];
         a.nRowBlocks = (L.h + a.rows - 1) / a.rows;
-        hipLaunchKernelGGL(pyr_resize_kernel, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
+        if (e->rszWide[l])
+            hipLaunchKernelGGL(pyr_resize_kernel<true>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(pyr_resize_kernel<false>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
     }
     // K3: FAST over every cell of every level
     HIPCHK(hipMemsetAsync(e->dCounters.p, 0, e->countersBytes, st));

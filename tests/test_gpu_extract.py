@@ -140,3 +140,53 @@ def test_batch_device_matches_single(tmp_path):
         kg = kps_h[f, :n].copy().view(capi.KP_DTYPE).reshape(-1)
         assert np.array_equal(kg, ko), f
         assert np.array_equal(desc_h[f, :n], do), f
+
+
+def _stage_check(img, nfeatures, scale, nlevels, ini_th=20, min_th=7):
+    g = capi.ORBextractor(nfeatures, scale, nlevels, ini_th, min_th)
+    o = O.OracleExtractor(nfeatures, scale, nlevels, ini_th, min_th)
+    kg, dg = g(img)
+    ko, do = o.extract(img)
+    for l in range(nlevels):
+        assert np.array_equal(g.debug_stage(l, 0), o.level(l)), f"pyramid level {l}"
+        cg, co = g.debug_stage(l, 2), o.candidates(l)
+        assert cg.shape == co.shape and np.array_equal(cg, co), f"FAST candidates level {l}"
+        bo = o.blurred(l)
+        if bo is not None:
+            assert np.array_equal(g.debug_stage(l, 1), bo), f"blurred level {l}"
+    assert np.array_equal(kg, ko)
+    assert np.array_equal(dg, do)
+    return len(kg)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (401, 301), (512, 512), (1280, 720), (1920, 1080), (1024, 96), (1283, 377),
+                                 (1216, 352), (250, 1100)])
+def test_odd_sizes(w, h):
+    """Widths that are / are not multiples of 4, 64 and of the strip widths (pitch == w, partial last strips, packed FAST
+    remainders, tall narrow levels); every stage bit-exact."""
+    nlevels = 8
+    # the reference needs >= one 30-px cell on the smallest level and a landscape-or-square detection area (nIni >= 1)
+    while nlevels > 1 and (min(w, h) / 1.2 ** (nlevels - 1) < 70):
+        nlevels -= 1
+    img = synth.textured_image(w, h, synth.BASE_SEED + w + h)
+    if w < h:   # portrait: the reference's nIni = round(W/H) is 0 and it divides by it (:543-545); the library refuses
+        with pytest.raises(capi.OrbfeError):
+            capi.ORBextractor(1500, 1.2, nlevels, 20, 7)(img)
+        return
+    assert _stage_check(img, 1500, 1.2, nlevels) > 300
+
+
+@pytest.mark.parametrize("scale,nlevels", [(1.1, 10), (1.25, 6), (1.5, 5), (2.0, 4), (1.2, 1), (1.2, 12), (1.33, 7)])
+def test_scale_factors_and_level_counts(scale, nlevels):
+    """The resize kernel's 8-byte source window and row-block choice depend on the scale factor (wide 12-byte variant from ~2 on)."""
+    w, h = (1241, 376) if scale ** (nlevels - 1) < 4.5 else (2048, 1024)   # the smallest level must hold a FAST cell
+    img = synth.textured_image(w, h, synth.BASE_SEED + int(scale * 100) + nlevels)
+    assert _stage_check(img, 1200, scale, nlevels) > 300
+
+
+@pytest.mark.parametrize("ini_th,min_th", [(20, 7), (40, 5), (7, 7), (100, 30), (5, 20)])
+def test_fast_thresholds(ini_th, min_th):
+    """Per-cell iniTh -> minTh fallback for different threshold pairs (incl. ini < min, which the reference also accepts)."""
+    img = synth.textured_image(752, 480, synth.BASE_SEED + 500 + ini_th)
+    img[:, :200] = (img[:, :200].astype(np.int32) // 8 + 100).astype(np.uint8)      # low-contrast band: cells that fall back
+    _stage_check(img, 1000, 1.2, 8, ini_th, min_th)
