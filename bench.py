@@ -272,6 +272,7 @@ def main():
         def hstep():
             if world > 1:
                 dist.broadcast(q, src=0)
+                torch.cuda.synchronize()      # the matcher runs on its own non-blocking stream: order it after the broadcast
             m.knn2_device(q.data_ptr(), NQ, db.data_ptr(), shard, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
                           idx_base=rank * shard, sync=True)
             if world > 1:

@@ -10,6 +10,7 @@ constexpr int kEdge = 19;        // EDGE_THRESHOLD, reference src/ORBextractor.c
 constexpr int kMinBorder = 16;   // EDGE_THRESHOLD-3, :773
 constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, :73
 constexpr int kPitchAlign = 64;  // row pitch of every workspace image, bytes
+constexpr int kPitchSlack = 16;  // pitch >= w + kPitchSlack: the descriptor kernel's 16-byte window loads may run past w
 
 // Geometry of one pyramid level for a given input size (host-built, passed to kernels by value).
 struct LevelGeom {

@@ -112,8 +112,9 @@ constexpr int kDescKpPerWave = 16;
 constexpr int kDescKpPerGroup = 4 * kDescKpPerWave;
 constexpr int kDescWinR = 18;                              // rotated taps reach at most round(hypot(13,13)) = 18 pixels
 constexpr int kDescWinRows = 2 * kDescWinR + 1;            // 37
-constexpr int kDescWinDw = 10;                             // 37 bytes + up to 3 bytes of alignment slack
-constexpr int kDescMomentDw = 31 * 9;                      // dwords of the 31 x 36 moment window
+constexpr int kDescWinDw = 12;                             // LDS row: 3 x 16 bytes (37 bytes + up to 3 of alignment slack used)
+constexpr int kDescWinItems = kDescWinRows * 3;            // 16-byte loads of the blurred window (111: two per lane)
+constexpr int kDescMomentItems = 31 * 3;                   // 16-byte loads of the 31 x 36 moment window (93: two per lane)
 
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
@@ -129,14 +130,21 @@ typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;
 __device__ __forceinline__ uint32_t gload_u32(gptr_u8 base, uint32_t off) {
     return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(base + off);
 }
+__device__ __forceinline__ uint4 gload_u32x4(gptr_u8 base, uint32_t off) {   // dword-aligned 16 bytes
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(4))) V { u32x4 v; };
+    const u32x4 v = reinterpret_cast<const __attribute__((address_space(1))) V *>(base + off)->v;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 // wave-uniform global pointer from two lanes' halves
 __device__ __forceinline__ gptr_u8 gptr_from(int lo, int hi) {
     return (gptr_u8)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
-    __shared__ uint2 sMask[4][5][64];        // [alignment][dword slot][lane]: (01-mask, (u+18)-weights) of the disc
-    __shared__ uint32_t sWin[4][6 * 64];     // per wave: the blurred window, row-major, kDescWinDw dwords per row
+    // [alignment][slot][lane][dword]: (01-mask, (u+18)-weights) of the disc for the dwords of the lane's 16-byte load
+    __shared__ __align__(16) uint2 sMask[4][2][64][4];
+    __shared__ __align__(16) uint32_t sWin[4][kDescWinRows * kDescWinDw];   // per wave: the blurred window, 48-byte rows
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (private L2s), so block id % 8 selects
     // the XCD.  All blocks of frame f get ids with id % 8 == f % 8: a frame's patches then stay in ONE 4-MiB L2 instead
@@ -146,19 +154,27 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     const int grp = (bid >> 3) % a.groupsPerFrame;
     if (f >= a.nFrames) return;   // whole workgroup
 
-    for (int e = threadIdx.x; e < 4 * 5 * 64; e += 256) {
-        const int al = e / 320, rem = e - al * 320, k5 = rem >> 6, ln = rem & 63;
-        const int it = ln + 64 * k5, row = it / 9, dc = it - row * 9, v = row - kHalfPatch;
-        const int dmax = it < kDescMomentDw ? c_umax[v < 0 ? -v : v] : -1;
-        uint32_t m01 = 0, mU = 0;
+    // The 31 x 36-byte moment window is fetched as three 16-byte pieces per row, at dwords 0, 4 and 5 of the row (the
+    // third overlaps the second so that nothing is read past byte 35); the overlapped dwords get zero masks.
+    for (int e = threadIdx.x; e < 4 * 2 * 64; e += 256) {
+        const int al = e >> 7, slot = (e >> 6) & 1, ln = e & 63;
+        const int it = ln + 64 * slot, row = it / 3, ch = it - row * 3, v = row - kHalfPatch;
+        const int dmax = it < kDescMomentItems ? c_umax[v < 0 ? -v : v] : -1;
+        const int dw0 = ch == 0 ? 0 : ch == 1 ? 4 : 5;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int u = 4 * dc - kHalfPatch - al + b;
-            const bool ok = u >= -dmax && u <= dmax;
-            m01 |= (ok ? 1u : 0u) << (8 * b);
-            mU |= (ok ? (uint32_t)(u + 18) : 0u) << (8 * b);
+        for (int q = 0; q < 4; q++) {
+            const int dc = dw0 + q;
+            const bool dup = ch == 2 && q < 3;   // dwords 5..7 already belong to piece 1
+            uint32_t m01 = 0, mU = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int u = 4 * dc - kHalfPatch - al + b;
+                const bool ok = !dup && u >= -dmax && u <= dmax;
+                m01 |= (ok ? 1u : 0u) << (8 * b);
+                mU |= (ok ? (uint32_t)(u + 18) : 0u) << (8 * b);
+            }
+            sMask[al][slot][ln][q] = make_uint2(m01, mU);
         }
-        sMask[al][k5][ln] = make_uint2(m01, mU);
     }
     __syncthreads();
 
@@ -200,27 +216,27 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     const int blurLo = (int)(uint32_t)blurV, blurHi = (int)(uint32_t)(blurV >> 32);
 
     // ---- phase 1: moments
-    int mRow[5], mDc4[5], mV[5];
+    int mRow[2], mOff[2], mV[2];
 #pragma unroll
-    for (int k5 = 0; k5 < 5; k5++) {
-        const int it = lane + 64 * k5, row = it / 9, dc = it - row * 9;
-        const bool in = it < kDescMomentDw;
-        mRow[k5] = in ? row : 0;          // slots past the window read a legal address and carry a zero mask
-        mDc4[k5] = in ? 4 * dc : 0;
-        mV[k5] = in ? row - kHalfPatch : 0;
-        asm volatile("" : "+v"(mRow[k5]), "+v"(mDc4[k5]), "+v"(mV[k5]));   // hold them, do not re-derive per keypoint
+    for (int sl = 0; sl < 2; sl++) {
+        const int it = lane + 64 * sl, row = it / 3, ch = it - row * 3;
+        const bool in = it < kDescMomentItems;
+        mRow[sl] = in ? row : 0;          // items past the window read a legal address and carry zero masks
+        mOff[sl] = in ? (ch == 0 ? 0 : ch == 1 ? 16 : 20) : 0;
+        mV[sl] = in ? row - kHalfPatch : 0;
+        asm volatile("" : "+v"(mRow[sl]), "+v"(mOff[sl]), "+v"(mV[sl]));   // hold them, do not re-derive per keypoint
     }
     int m10V = 0, m01V = 0;
-    auto moment_loads = [&](int k, uint32_t (&dw)[5]) {
+    auto moment_loads = [&](int k, uint4 (&dw)[2]) {
         const int cx = rl(cxV, k), cy = rl(cyV, k), pitch = rl(pitchV, k);
         const gptr_u8 base = gptr_from(rl(imgLo, k), rl(imgHi, k)) + (size_t)(cy - kHalfPatch) * pitch +
-                             ((cx - kHalfPatch) & ~3);   // xa >= 4; xa + 35 < pitch
+                             ((cx - kHalfPatch) & ~3);   // xa >= 4; xa + 35 <= cx + 20 <= w
 #pragma unroll
-        for (int k5 = 0; k5 < 5; k5++)
-            dw[k5] = gload_u32(base, __umul24((uint32_t)mRow[k5], (uint32_t)pitch) + (uint32_t)mDc4[k5]);
+        for (int sl = 0; sl < 2; sl++)
+            dw[sl] = gload_u32x4(base, __umul24((uint32_t)mRow[sl], (uint32_t)pitch) + (uint32_t)mOff[sl]);
     };
     {
-        uint32_t dw[5], nx[5];
+        uint4 dw[2], nx[2];
         moment_loads(0, dw);
         for (int k = 0; k < nValid; k++) {
             if (k + 1 < nValid) moment_loads(k + 1, nx);
@@ -228,19 +244,26 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
             uint32_t A = 0;
             int rsSum = 0, m01 = 0;
 #pragma unroll
-            for (int k5 = 0; k5 < 5; k5++) {
-                const uint2 mk = sMask[al][k5][lane];
-                const uint32_t rs = __builtin_amdgcn_udot4(dw[k5], mk.x, 0u, false);
-                A = __builtin_amdgcn_udot4(dw[k5], mk.y, A, false);
+            for (int sl = 0; sl < 2; sl++) {
+                const uint4 *mk = reinterpret_cast<const uint4 *>(sMask[al][sl][lane]);
+                const uint4 m0 = mk[0], m1 = mk[1];   // (m01, mU) of dwords 0,1 and 2,3
+                uint32_t rs = __builtin_amdgcn_udot4(dw[sl].x, m0.x, 0u, false);
+                rs = __builtin_amdgcn_udot4(dw[sl].y, m0.z, rs, false);
+                rs = __builtin_amdgcn_udot4(dw[sl].z, m1.x, rs, false);
+                rs = __builtin_amdgcn_udot4(dw[sl].w, m1.z, rs, false);
+                A = __builtin_amdgcn_udot4(dw[sl].x, m0.y, A, false);
+                A = __builtin_amdgcn_udot4(dw[sl].y, m0.w, A, false);
+                A = __builtin_amdgcn_udot4(dw[sl].z, m1.y, A, false);
+                A = __builtin_amdgcn_udot4(dw[sl].w, m1.w, A, false);
                 rsSum += (int)rs;
-                m01 += __mul24(mV[k5], (int)rs);
+                m01 += __mul24(mV[sl], (int)rs);
             }
             const int m10 = (int)A - 18 * rsSum;
             const int s10 = wave_sum_uniform(m10), s01 = wave_sum_uniform(m01);
             m10V = lane == k ? s10 : m10V;
             m01V = lane == k ? s01 : m01V;
 #pragma unroll
-            for (int k5 = 0; k5 < 5; k5++) dw[k5] = nx[k5];
+            for (int sl = 0; sl < 2; sl++) dw[sl] = nx[sl];
         }
     }
 
@@ -265,14 +288,16 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     }
 
     // ---- phase 3: rBRIEF on the blurred level
-    int wRow[6], wDc4[6];
+    // the 37 x 40-byte window of the blurred level: three 16-byte pieces per row (the blurred rows have >= 16 bytes of
+    // pitch slack, so the last piece may run past byte 39), written to 48-byte LDS rows
+    int wRow[2], wOff[2];
 #pragma unroll
-    for (int k6 = 0; k6 < 6; k6++) {
-        const int it = lane + 64 * k6, row = it / kDescWinDw, dc = it - row * kDescWinDw;
-        const bool in = it < kDescWinRows * kDescWinDw;
-        wRow[k6] = in ? row : 0;
-        wDc4[k6] = in ? 4 * dc : 0;
-        asm volatile("" : "+v"(wRow[k6]), "+v"(wDc4[k6]));
+    for (int sl = 0; sl < 2; sl++) {
+        const int it = lane + 64 * sl, row = it / 3, ch = it - row * 3;
+        const bool in = it < kDescWinItems;
+        wRow[sl] = in ? row : 0;
+        wOff[sl] = in ? 16 * ch : 0;
+        asm volatile("" : "+v"(wRow[sl]), "+v"(wOff[sl]));
     }
     float px0[4], py0[4], px1[4], py1[4];
     {
@@ -287,22 +312,23 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
         }
     }
     const int caI = __builtin_bit_cast(int, caV), sbI = __builtin_bit_cast(int, sbV);
-    auto window_loads = [&](int k, uint32_t (&dw)[6]) {
+    auto window_loads = [&](int k, uint4 (&dw)[2]) {
         const int cx = rl(cxV, k), cy = rl(cyV, k), bp = rl(bpV, k);
-        const int xa = (cx - kDescWinR) & ~3;           // >= 0
+        const int xa = (cx - kDescWinR) & ~3;           // >= 0; xa + 47 <= w + 9 < pitch (common.h: kPitchSlack)
         const gptr_u8 base = gptr_from(rl(blurLo, k), rl(blurHi, k)) + (size_t)(cy - kDescWinR) * bp + xa;
-        const int dcMax = bp - 4 - xa;                  // the slack dword of a window at the right edge stays inside the row
 #pragma unroll
-        for (int k6 = 0; k6 < 6; k6++)
-            dw[k6] = gload_u32(base, __umul24((uint32_t)wRow[k6], (uint32_t)bp) + (uint32_t)min(wDc4[k6], dcMax));
+        for (int sl = 0; sl < 2; sl++) dw[sl] = gload_u32x4(base, __umul24((uint32_t)wRow[sl], (uint32_t)bp) + (uint32_t)wOff[sl]);
     };
     {
-        uint32_t dw[6], nx[6];
+        uint4 dw[2], nx[2];
         window_loads(0, dw);
         const uint8_t *win = reinterpret_cast<const uint8_t *>(sWin[wv]);
         for (int k = 0; k < nValid; k++) {
-#pragma unroll
-            for (int k6 = 0; k6 < 6; k6++) sWin[wv][lane + 64 * k6] = dw[k6];
+            {
+                uint4 *w4 = reinterpret_cast<uint4 *>(sWin[wv]);   // item it = 3 * row + piece sits at 16 * it bytes
+                w4[lane] = dw[0];
+                if (lane + 64 < kDescWinItems) w4[lane + 64] = dw[1];
+            }
             if (k + 1 < nValid) window_loads(k + 1, nx);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -333,8 +359,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
             uint8_t *dout = a.desc + ((size_t)f * a.cap + iBase + k) * 32;
             if ((lane & 7) == 0) *reinterpret_cast<uint32_t *>(dout + (lane >> 3) * 4) = v;
             __builtin_amdgcn_wave_barrier();   // the next keypoint's window overwrites sWin
-#pragma unroll
-            for (int k6 = 0; k6 < 6; k6++) dw[k6] = nx[k6];
+            dw[0] = nx[0];
+            dw[1] = nx[1];
         }
     }
 }

@@ -236,7 +236,7 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
         const float scale = e->mvInvScaleFactor[l];
         L.w = cv_round((float)w * scale);   // reference src/ORBextractor.cc:1111-1112
         L.h = cv_round((float)h * scale);
-        L.pitch = round_up(L.w, kPitchAlign);
+        L.pitch = round_up(L.w + kPitchSlack, kPitchAlign);
         if (L.w > 65535 || L.h > 65535) return fail(ORBFE_ERR_UNSUPPORTED, "image larger than 65535 pixels on a side");
         L.pyrOff = pyrOff;
         if (l > 0) pyrOff += round_up(L.pitch * L.h, 256);
