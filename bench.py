@@ -132,6 +132,29 @@ def other_configs(local_rank, dev):
         "pairs_per_s_sequential": round(1.0 / float(np.median(lat)), 1),
         "left_keypoints": int(n[0]), "right_keypoints": int(n[1]),
         "points_with_depth": int((dep[:int(n[0])] > 0).sum().item())}
+    # DBoW2 transform (N2): tree descent of ORB descriptors down a synthetic 10-ary, 6-level vocabulary (the ORBvoc.txt
+    # shape: 1.1 M nodes, 10^6 words), one frame's worth and a 512-frame batch
+    co, ci, nd, _wi, _w = synth.regular_vocabulary(10, 6, 31337)
+    voc = capi.Vocabulary(co, ci, nd, 6, device=local_rank)
+    nbig = 512 * 2000
+    feats = torch.from_numpy(synth.random_descriptors(nbig, 99)).to(dev)
+    leaf = torch.zeros(nbig, dtype=torch.int32, device=dev)
+    nid = torch.zeros(nbig, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        m.bow_transform_device(voc, feats.data_ptr(), nbig, 4, leaf.data_ptr(), nid.data_ptr(), sync=True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m.bow_transform_device(voc, feats.data_ptr(), nbig, 4, leaf.data_ptr(), nid.data_ptr(), sync=False)
+    m.synchronize()
+    big = (time.perf_counter() - t0) / 5
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        m.bow_transform_device(voc, feats.data_ptr(), 2000, 4, leaf.data_ptr(), nid.data_ptr(), sync=True)
+        lat.append(time.perf_counter() - t0)
+    out["bow_transform_k10_L6"] = {"descriptors_per_s_batched": round(nbig / big, 1), "batch_descriptors": nbig,
+                                   "latency_ms_2000_descriptors": round(float(np.median(lat)) * 1e3, 4),
+                                   "hamming_distances_per_descriptor": 60}
     return out
 
 

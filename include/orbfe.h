@@ -182,6 +182,20 @@ int orbfe_stereo_rowband(orbfe_matcher *m, const orbfe_keypoint *dev_kl, const u
 int orbfe_stereo_match(orbfe_matcher *m, orbfe_extractor *left, int left_frame, orbfe_extractor *right, int right_frame,
                        const orbfe_keypoint *dev_kl, const uint8_t *dev_dl, int nl, const orbfe_keypoint *dev_kr,
                        const uint8_t *dev_dr, int nr, float mbf, float mb, float *dev_uright, float *dev_depth, int sync);
+/* The tree descent of DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform (reference
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259, called per feature from :1127-1200 by Frame::ComputeBoW,
+ * src/Frame.cc:395-402, and KeyFrame::ComputeBoW).  The vocabulary is handed over as flat host arrays: node 0 is the
+ * root, the children of node i are child_idx[child_off[i] .. child_off[i+1]) in m_nodes[i].children order (ids larger
+ * than i), node_desc holds 32 bytes per node, a node without children is a leaf; depth_L = m_L. */
+typedef struct orbfe_vocab orbfe_vocab;
+int orbfe_vocab_create(int device, int n_nodes, const int32_t *child_off, const int32_t *child_idx, const uint8_t *node_desc,
+                       int depth_L, orbfe_vocab **out);
+int orbfe_vocab_destroy(orbfe_vocab *v);
+/* per feature i: dev_leaf_node[i] = the leaf the descent ends in (the host maps it to word id and weight),
+ * dev_nid[i] = the node passed at level depth_L - levelsup (0 when that level is <= 0; also 0 when the walk ends above
+ * that level, where the reference leaves the value unset).  FORB::distance, strict '<': the first minimum wins. */
+int orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocab *v, const uint8_t *dev_desc, int n, int levelsup,
+                        int32_t *dev_leaf_node, int32_t *dev_nid, int sync);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

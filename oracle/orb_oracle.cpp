@@ -35,6 +35,7 @@
 #include <list>
 #include <thread>
 #include <utility>
+#include <map>
 #include <vector>
 
 namespace {
@@ -918,6 +919,73 @@ void orc_stereo_full(const orc_extractor *el, const orc_extractor *er, const orc
         mvuRight[vDistIdx[i].second] = -1;
         mvDepth[vDistIdx[i].second] = -1;
     }
+}
+
+/* ------------------------------------------------------------ DBoW2 transform */
+/* FORB::distance, Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101 (the same SWAR popcount as ORBmatcher::DescriptorDistance) */
+static void bow_descend_one(const int32_t *child_off, const int32_t *child_idx, const uint8_t *node_desc, int L, const uint8_t *feature,
+                            int levelsup, int32_t *leaf, int32_t *nid) {
+    /* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup), TemplatedVocabulary.h:1218-1259 */
+    const int nid_level = L - levelsup;
+    *nid = 0;   /* :1227 sets it only when nid_level <= 0; otherwise :1250 does, if the descent reaches that level */
+    int32_t final_id = 0;
+    int current_level = 0;
+    do {
+        ++current_level;
+        const int32_t c0 = child_off[final_id], c1 = child_off[final_id + 1];
+        if (c0 == c1) break;   /* a root without children: the reference would index an empty vector */
+        int32_t best = child_idx[c0];
+        double best_d = hamming(feature, node_desc + (size_t)best * 32);
+        for (int32_t c = c0 + 1; c < c1; c++) {
+            const int32_t id = child_idx[c];
+            const double d = hamming(feature, node_desc + (size_t)id * 32);
+            if (d < best_d) { best_d = d; best = id; }
+        }
+        final_id = best;
+        if (current_level == nid_level) *nid = final_id;
+    } while (child_off[final_id] != child_off[final_id + 1]);
+    *leaf = final_id;
+}
+
+void orc_bow_descend(const int32_t *child_off, const int32_t *child_idx, const uint8_t *node_desc, int L, const uint8_t *desc, int n,
+                     int levelsup, int32_t *leaf, int32_t *nid) {
+    for (int i = 0; i < n; i++) bow_descend_one(child_off, child_idx, node_desc, L, desc + (size_t)i * 32, levelsup, &leaf[i], &nid[i]);
+}
+
+void orc_bow_transform(const int32_t *child_off, const int32_t *child_idx, const uint8_t *node_desc, const int32_t *word_id,
+                       const double *weight, int L, int weighting, int norm, const uint8_t *desc, int n, int levelsup,
+                       int32_t *bow_ids, double *bow_vals, int32_t *n_bow, int32_t *fv_node, int32_t *fv_feat, int32_t *n_fv) {
+    /* TemplatedVocabulary::transform(features, v, fv, levelsup), TemplatedVocabulary.h:1127-1200 */
+    std::map<unsigned, double> v;                       /* BowVector */
+    std::map<unsigned, std::vector<unsigned>> fv;       /* FeatureVector */
+    const bool tf = weighting == 0 || weighting == 1;   /* TF_IDF or TF */
+    for (int i = 0; i < n; i++) {
+        int32_t leaf, nid;
+        bow_descend_one(child_off, child_idx, node_desc, L, desc + (size_t)i * 32, levelsup, &leaf, &nid);
+        const unsigned id = (unsigned)word_id[leaf];
+        const double w = weight[leaf];
+        if (w > 0) {   /* not stopped */
+            if (tf) v[id] += w;                          /* BowVector::addWeight, BowVector.cpp:34-46 */
+            else v.insert(std::make_pair(id, w));        /* addIfNotExist, :50-58 */
+            fv[(unsigned)nid].push_back((unsigned)i);    /* FeatureVector::addFeature, FeatureVector.cpp:29-43 */
+        }
+    }
+    if (tf && !v.empty() && norm == 0) {                 /* :1160-1166 */
+        const double nd = (double)v.size();
+        for (auto &kv : v) kv.second /= nd;
+    }
+    if (norm != 0) {                                     /* BowVector::normalize, BowVector.cpp:62-84 */
+        double s = 0.0;
+        if (norm == 1) { for (auto &kv : v) s += std::fabs(kv.second); }
+        else { for (auto &kv : v) s += kv.second * kv.second; s = std::sqrt(s); }
+        if (s > 0.0) for (auto &kv : v) kv.second /= s;
+    }
+    int k = 0;
+    for (auto &kv : v) { bow_ids[k] = (int32_t)kv.first; bow_vals[k] = kv.second; k++; }
+    *n_bow = k;
+    k = 0;
+    for (auto &kv : fv) for (unsigned f : kv.second) { fv_node[k] = (int32_t)kv.first; fv_feat[k] = (int32_t)f; k++; }
+    *n_fv = k;
 }
 
 /* ------------------------------------------------------------ CPU baseline */

@@ -88,6 +88,20 @@ void orc_stereo_rowband(const orc_keypoint *kl, const uint8_t *dl, int nl, const
 void orc_stereo_full(const orc_extractor *el, const orc_extractor *er, const orc_keypoint *kl, const uint8_t *dl, int nl,
                      const orc_keypoint *kr, const uint8_t *dr, int nr, float bf, float b, float *u_right, float *depth);
 
+/* ---- DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) ----
+ * The vocabulary tree as flat arrays: node 0 is the root, the children of node i are child_idx[child_off[i] .. child_off[i+1])
+ * in m_nodes[i].children order, node_desc holds 32 bytes per node, a node without children is a leaf (isLeaf()). */
+/* tree descent of one feature (:1218-1259): leaf[i] = final node id, nid[i] = node at level L - levelsup (0 when that level
+ * is <= 0; the reference leaves *nid unset when the descent ends above that level -- pinned to 0 here) */
+void orc_bow_descend(const int32_t *child_off, const int32_t *child_idx, const uint8_t *node_desc, int L, const uint8_t *desc, int n,
+                     int levelsup, int32_t *leaf, int32_t *nid);
+/* the whole transform(features, BowVector, FeatureVector, levelsup) (:1127-1200): weighting 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY;
+ * norm 0 none, 1 L1, 2 L2 (ScoringObject::mustNormalize).  bow_ids/bow_vals: the BowVector in map order (capacity n);
+ * fv_node/fv_feat: the FeatureVector flattened in map order, features of a node in insertion order (capacity n). */
+void orc_bow_transform(const int32_t *child_off, const int32_t *child_idx, const uint8_t *node_desc, const int32_t *word_id,
+                       const double *weight, int L, int weighting, int norm, const uint8_t *desc, int n, int levelsup,
+                       int32_t *bow_ids, double *bow_vals, int32_t *n_bow, int32_t *fv_node, int32_t *fv_feat, int32_t *n_fv);
+
 /* time n_frames calls of orc_extract over `threads` threads (one frame per thread at a time); returns seconds */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps);

@@ -28,6 +28,7 @@ EXPORTS = [
     "orbfe_hamming", "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_match_knn2", "orbfe_match_csr",
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
+    "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -87,6 +88,9 @@ def lib():
                                        vp, vp, C.c_int]
     L.orbfe_stereo_match.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp,
                                      C.c_int]
+    L.orbfe_vocab_create.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.POINTER(vp)]
+    L.orbfe_vocab_destroy.argtypes = [vp]
+    L.orbfe_bow_transform.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
     L.orbfe_matcher_synchronize.argtypes = [vp]
     L.orbfe_matcher_stream.restype = vp
     L.orbfe_matcher_stream.argtypes = [vp]
@@ -284,11 +288,39 @@ class ORBmatcher:
         check(self._L.orbfe_stereo_match(self._h, left._h, left_frame, right._h, right_frame, vp(kl_ptr), vp(dl_ptr), nl,
                                          vp(kr_ptr), vp(dr_ptr), nr, mbf, mb, vp(uright_ptr), vp(depth_ptr), 1 if sync else 0))
 
+    def bow_transform_device(self, vocab: "Vocabulary", desc_ptr, n, levelsup, leaf_ptr, nid_ptr, sync=True):
+        check(self._L.orbfe_bow_transform(self._h, vocab._h, vp(desc_ptr), n, levelsup, vp(leaf_ptr), vp(nid_ptr),
+                                          1 if sync else 0))
+
     def synchronize(self):
         check(self._L.orbfe_matcher_synchronize(self._h))
 
     def stream(self) -> int:
         return int(self._L.orbfe_matcher_stream(self._h) or 0)
+
+
+class Vocabulary:
+    """Device copy of a DBoW2 vocabulary tree (flat arrays, see include/orbfe.h: orbfe_vocab_create)."""
+
+    def __init__(self, child_off, child_idx, node_desc, depth_L, device=0):
+        self._L = lib()
+        self._h = vp()
+        co = np.ascontiguousarray(child_off, np.int32)
+        ci = np.ascontiguousarray(child_idx, np.int32)
+        nd = np.ascontiguousarray(node_desc, np.uint8)
+        check(self._L.orbfe_vocab_create(device, len(co) - 1, _np_ptr(co), _np_ptr(ci) if len(ci) else None, _np_ptr(nd),
+                                         depth_L, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbfe_vocab_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def merge_knn2(best_dist, best_idx, second_dist):

@@ -383,4 +383,45 @@ __global__ __launch_bounds__(1024) void stereo_gate_kernel(const int *__restrict
     }
 }
 
+// ---- DBoW2 vocabulary-tree descent (N2) -----------------------------------------------------------------------------
+// Replaces the per-feature loop of TemplatedVocabulary<FORB::TDescriptor, FORB>::transform (reference
+// Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259, distance = FORB::distance, FORB.cpp:81-101).  One feature per
+// lane: its 256 bits stay in 8 VGPRs while the lane walks from the root to a leaf; at every node the children's
+// descriptors are gathered (two 16-byte loads each), v_xor + v_bcnt, strict '<' so the first minimum wins as in the
+// reference.  Node ids grow from parent to child (checked on the host), so every walk ends.
+struct BowArgs {
+    const int32_t *childOff;   // [nNodes + 1]
+    const int32_t *childIdx;
+    const uint4 *nodeDesc;     // [nNodes][2]
+    int nNodes, L, levelsup;
+    const uint4 *desc;         // [n][2]
+    int n;
+    int32_t *leaf, *nid;
+};
+
+__global__ __launch_bounds__(256) void bow_descend_kernel(BowArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const uint4 q0 = a.desc[2 * (size_t)i], q1 = a.desc[2 * (size_t)i + 1];
+    const int nidLevel = a.L - a.levelsup;
+    int nid = 0, node = 0, level = 0;
+    for (int guard = 0; guard < 64; guard++) {
+        const int c0 = a.childOff[node], c1 = a.childOff[node + 1];
+        if (c0 == c1) break;   // leaf
+        ++level;
+        int best = 0, bestD = 0x7fffffff;
+        for (int c = c0; c < c1; c++) {
+            const int id = a.childIdx[c];
+            const uint4 d0 = a.nodeDesc[2 * (size_t)id], d1 = a.nodeDesc[2 * (size_t)id + 1];
+            const int d = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                          __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+            if (d < bestD) { bestD = d; best = id; }
+        }
+        node = best;
+        if (level == nidLevel) nid = node;
+    }
+    a.leaf[i] = node;
+    a.nid[i] = nid;
+}
+
 }  // namespace orbfe

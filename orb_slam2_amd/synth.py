@@ -144,3 +144,89 @@ def planted_queries(db: np.ndarray, nq: int, seed: int, planted_frac: float = 0.
                 v[b >> 3] ^= np.uint8(1 << (b & 7))
             q[i * (nq // n_pl)] = v
     return q
+
+
+def random_vocabulary(k: int, L: int, seed: int, irregular: bool = False):
+    """A synthetic DBoW2-style vocabulary tree as flat arrays (the ORBvoc.txt blob is not shipped with the reference).
+
+    Nodes are numbered breadth first (children ids > parent id, as DBoW2's create()/loadFromTextFile produce them).
+    A child's descriptor is its parent's with ~30 random bits flipped, so that descents are not arbitrary; a few siblings
+    are exact duplicates (ties: the first child must win).  ``irregular``: 1..k children per node and leaves at several
+    depths.  Returns child_off[n+1], child_idx, node_desc[n,32], word_id[n] (-1 for inner nodes), weight[n] (float64,
+    ~5 % of the words stopped with weight 0).
+    """
+    rng = SplitMix64(seed)
+    desc = [np.zeros(32, np.uint8)]
+    depth = [0]
+    children = [[]]
+    frontier = [0]
+    while frontier:
+        nxt = []
+        for p in frontier:
+            if depth[p] >= L:
+                continue
+            if irregular and depth[p] >= 1 and int(rng.integers(0, 8, 1)[0]) == 0:
+                continue                                   # an early leaf
+            nc = k if not irregular else 1 + int(rng.integers(0, k, 1)[0])
+            for c in range(nc):
+                d = desc[p].copy()
+                if depth[p] == 0:
+                    d = random_descriptors(1, int(rng.next_u64(1)[0] & 0x7FFFFFFF))[0]
+                else:
+                    bits = rng.integers(0, 256, 30)
+                    for b in bits:
+                        d[b >> 3] ^= np.uint8(1 << (b & 7))
+                if c > 0 and int(rng.integers(0, 16, 1)[0]) == 0:
+                    d = desc[children[p][-1]].copy()       # duplicate of the previous sibling
+                nid = len(desc)
+                desc.append(d)
+                depth.append(depth[p] + 1)
+                children.append([])
+                children[p].append(nid)
+                nxt.append(nid)
+        frontier = nxt
+    n = len(desc)
+    child_off = np.zeros(n + 1, np.int32)
+    for i in range(n):
+        child_off[i + 1] = child_off[i] + len(children[i])
+    child_idx = np.array([c for ch in children for c in ch], np.int32)
+    word_id = np.full(n, -1, np.int32)
+    weight = np.zeros(n, np.float64)
+    w = 0
+    for i in range(n):
+        if not children[i]:
+            word_id[i] = w
+            w += 1
+            u = float(rng.next_u64(1)[0] >> 11) / float(1 << 53)
+            weight[i] = 0.0 if u < 0.05 else 0.5 + 9.5 * u   # idf-like
+    return child_off, child_idx, np.stack(desc), word_id, weight
+
+
+def regular_vocabulary(k: int, L: int, seed: int):
+    """Full k-ary tree of depth L, built level by level with numpy (1.1 M nodes for k=10, L=6 in a few seconds): same
+    array layout as random_vocabulary, a child = its parent with 24 random bits flipped."""
+    rng = SplitMix64(seed)
+    levels = [np.zeros((1, 32), np.uint8)]
+    for lv in range(L):
+        par = np.repeat(levels[-1], k, axis=0)
+        n = len(par)
+        if lv == 0:
+            par = random_descriptors(n, seed ^ 0x5EED)
+        else:
+            par = par.copy()
+            for _ in range(24):
+                bit = rng.integers(0, 256, n)
+                par[np.arange(n), bit >> 3] ^= (1 << (bit & 7)).astype(np.uint8)
+        levels.append(par)
+    node_desc = np.concatenate(levels)
+    n = len(node_desc)
+    n_inner = n - len(levels[-1])
+    child_off = np.zeros(n + 1, np.int32)
+    child_off[1:n_inner + 1] = k * np.arange(1, n_inner + 1)
+    child_off[n_inner + 1:] = k * n_inner
+    child_idx = np.arange(1, n, dtype=np.int32)      # breadth-first numbering: node i's children are k*i+1 .. k*i+k
+    word_id = np.full(n, -1, np.int32)
+    word_id[n_inner:] = np.arange(n - n_inner)
+    u = (rng.next_u64(n) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    weight = np.where(np.arange(n) >= n_inner, np.where(u < 0.05, 0.0, 0.5 + 9.5 * u), 0.0)
+    return child_off, child_idx, node_desc, word_id, weight

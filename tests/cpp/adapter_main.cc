@@ -2,13 +2,18 @@
 // Frame::ExtractORB does (reference src/Frame.cc:247-253), on a raw 8-bit image file, and dumps the outputs so the
 // pytest driver can compare them with the oracle.  usage: adapter_main in.raw w h nfeatures out.bin
 //                                                          adapter_main stereo left.raw right.raw w h nfeatures bf b out.bin
+//                                                          adapter_main bow voc.txt desc.raw n levelsup out.bin
+// The bow mode loads a vocabulary in the ORBvoc.txt format and runs Frame::ComputeBoW's transform (src/Frame.cc:395-402).
 // The stereo mode follows the Frame stereo constructor (src/Frame.cc:59-93): two extractors, then ComputeStereoMatches.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include <map>
+
 #include "ORBextractor.h"
+#include "ORBVocabulary_orbfe.h"
 #include "ORBmatcher_orbfe.h"
 
 static bool read_raw(const char *path, std::vector<unsigned char> &buf) {
@@ -47,7 +52,32 @@ static int stereo_main(char **argv) {
     return 0;
 }
 
+static int bow_main(char **argv) {
+    const int n = std::atoi(argv[4]), levelsup = std::atoi(argv[5]);
+    std::vector<unsigned char> buf((size_t)n * 32);
+    if (!read_raw(argv[3], buf)) return 3;
+    orbfe::Vocabulary voc;
+    if (!voc.loadFromTextFile(argv[2])) { std::fprintf(stderr, "bow: cannot load %s: %s\n", argv[2], orbfe_last_error()); return 5; }
+    cv::Mat desc(n, 32, CV_8UC1, buf.data(), (size_t)32);
+    std::map<unsigned, double> bow;                          // DBoW2::BowVector
+    std::map<unsigned, std::vector<unsigned> > fv;           // DBoW2::FeatureVector
+    if (voc.transform(desc, bow, fv, levelsup) != 0) { std::fprintf(stderr, "bow: %s\n", orbfe_last_error()); return 6; }
+    FILE *fo = std::fopen(argv[6], "wb");
+    if (!fo) return 4;
+    int nb = (int)bow.size(), nf = 0;
+    for (auto &kv : fv) nf += (int)kv.second.size();
+    std::fwrite(&nb, 4, 1, fo);
+    std::fwrite(&nf, 4, 1, fo);
+    for (auto &kv : bow) { int id = (int)kv.first; std::fwrite(&id, 4, 1, fo); }
+    for (auto &kv : bow) std::fwrite(&kv.second, 8, 1, fo);
+    for (auto &kv : fv) for (unsigned ft : kv.second) { int a = (int)kv.first, b = (int)ft; std::fwrite(&a, 4, 1, fo); std::fwrite(&b, 4, 1, fo); }
+    std::fclose(fo);
+    std::printf("adapter bow ok: %d words, %d features in %d nodes\n", nb, nf, (int)fv.size());
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 7 && std::strcmp(argv[1], "bow") == 0) return bow_main(argv);
     if (argc >= 10 && std::strcmp(argv[1], "stereo") == 0) return stereo_main(argv);
     if (argc < 6) return 2;
     const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), nf = std::atoi(argv[4]);

@@ -66,6 +66,12 @@ def lib():
                                          C.c_float, i32p, i32p]
         L.orc_stereo_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u8p, C.c_int, C.c_void_p, u8p, C.c_int,
                                       C.c_float, C.c_float, f32p, f32p]
+        L.orc_bow_descend.argtypes = [i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p, i32p]
+        L.orc_bow_descend.restype = None
+        L.orc_bow_transform.argtypes = [i32p, i32p, u8p, i32p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, u8p, C.c_int,
+                                        C.c_int, i32p, C.POINTER(C.c_double), C.POINTER(C.c_int32), i32p, i32p,
+                                        C.POINTER(C.c_int32)]
+        L.orc_bow_transform.restype = None
         L.orc_time_extract.restype = C.c_double
         L.orc_time_extract.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long)]
@@ -255,6 +261,32 @@ def stereo_full(el: OracleExtractor, er: OracleExtractor, kl, dl, kr, dr, bf, b)
     lib().orc_stereo_full(el.h, er.h, kl.ctypes.data_as(C.c_void_p), _ptr(dl, u8p), len(kl),
                           kr.ctypes.data_as(C.c_void_p), _ptr(dr, u8p), len(kr), bf, b, _ptr(ur, f32p), _ptr(dep, f32p))
     return ur, dep
+
+
+def bow_descend(child_off, child_idx, node_desc, L, desc, levelsup):
+    co, ci = np.ascontiguousarray(child_off, np.int32), np.ascontiguousarray(child_idx, np.int32)
+    nd, d = np.ascontiguousarray(node_desc, np.uint8), np.ascontiguousarray(desc, np.uint8)
+    n = len(d)
+    leaf, nid = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lib().orc_bow_descend(_ptr(co, i32p), _ptr(ci, i32p), _ptr(nd, u8p), L, _ptr(d, u8p), n, levelsup, _ptr(leaf, i32p),
+                          _ptr(nid, i32p))
+    return leaf, nid
+
+
+def bow_transform(child_off, child_idx, node_desc, word_id, weight, L, weighting, norm, desc, levelsup):
+    """-> (bow_ids, bow_vals), (fv_node, fv_feat): BowVector and flattened FeatureVector in map order."""
+    co, ci = np.ascontiguousarray(child_off, np.int32), np.ascontiguousarray(child_idx, np.int32)
+    nd, d = np.ascontiguousarray(node_desc, np.uint8), np.ascontiguousarray(desc, np.uint8)
+    wi, w = np.ascontiguousarray(word_id, np.int32), np.ascontiguousarray(weight, np.float64)
+    n = len(d)
+    bi, bv = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+    fn, ff = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    nb, nf = C.c_int32(0), C.c_int32(0)
+    lib().orc_bow_transform(_ptr(co, i32p), _ptr(ci, i32p), _ptr(nd, u8p), _ptr(wi, i32p),
+                            w.ctypes.data_as(C.POINTER(C.c_double)), L, weighting, norm, _ptr(d, u8p), n, levelsup,
+                            _ptr(bi, i32p), bv.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nb), _ptr(fn, i32p),
+                            _ptr(ff, i32p), C.byref(nf))
+    return (bi[:nb.value].copy(), bv[:nb.value].copy()), (fn[:nf.value].copy(), ff[:nf.value].copy())
 
 
 def time_extract(frames: np.ndarray, nfeatures, scale_factor, nlevels, ini_th, min_th, threads, reps=1):

@@ -61,3 +61,38 @@ def test_cpp_stereo_matcher_matches_oracle(tmp_path):
     assert n == len(kl) and (ref_dep > 0).sum() > 200
     assert np.array_equal(ur.view(np.uint32), ref_ur.view(np.uint32))
     assert np.array_equal(dep.view(np.uint32), ref_dep.view(np.uint32))
+
+
+def test_cpp_vocabulary_transform_matches_oracle(tmp_path):
+    """orbfe::Vocabulary (include/ORBVocabulary_orbfe.h): loadFromTextFile in the ORBvoc.txt format, then
+    transform(descriptors, BowVector, FeatureVector, 4) as Frame::ComputeBoW calls it; doubles bit-exact."""
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    assert exe.exists()
+    k, L, levelsup = 10, 4, 2
+    co, ci, nd, wi, w = synth.random_vocabulary(k, L, 4242)
+    parent = np.zeros(len(nd), np.int64)
+    for p in range(len(nd)):
+        parent[ci[co[p]:co[p + 1]]] = p
+    voc = tmp_path / "voc.txt"
+    with open(voc, "w") as fh:
+        fh.write(f"{k} {L} 0 0\n")                             # L1_NORM, TF_IDF: what ORBvoc.txt declares
+        for i in range(1, len(nd)):
+            fh.write(f"{parent[i]} {1 if wi[i] >= 0 else 0} " + " ".join(str(int(b)) for b in nd[i]) + f" {float(w[i])!r}\n")
+    img = synth.textured_image(752, 480, synth.BASE_SEED + 17)
+    _, desc = O.OracleExtractor(1200, 1.2, 8, 20, 7).extract(img)      # real ORB descriptors as features
+    n = len(desc)
+    raw, out = tmp_path / "desc.raw", tmp_path / "out.bin"
+    raw.write_bytes(np.ascontiguousarray(desc).tobytes())
+    r = subprocess.run([str(exe), "bow", str(voc), str(raw), str(n), str(levelsup), str(out)], capture_output=True, text=True,
+                       timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    nb, nf = np.frombuffer(buf, np.int32, 2)
+    ids = np.frombuffer(buf, np.int32, nb, 8)
+    vals = np.frombuffer(buf, np.float64, nb, 8 + 4 * nb)
+    fv = np.frombuffer(buf, np.int32, 2 * nf, 8 + 12 * nb).reshape(nf, 2)
+    (rids, rvals), (rfn, rff) = O.bow_transform(co, ci, nd, wi, w, L, 0, 1, desc, levelsup)
+    assert nb == len(rids) > 50 and np.array_equal(ids, rids)
+    assert np.array_equal(vals.view(np.uint64), rvals.view(np.uint64))  # bit-exact doubles
+    assert np.array_equal(fv[:, 0], rfn) and np.array_equal(fv[:, 1], rff)
+    assert abs(vals.sum() - 1.0) < 1e-12                                # L1-normalised

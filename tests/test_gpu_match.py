@@ -188,3 +188,36 @@ def test_stereo_match_no_matches_and_argument_errors():
     with pytest.raises(capi.OrbfeError):
         m.stereo_match_device(g, 0, fresh, 0, dk.data_ptr(), dd.data_ptr(), len(k), dk.data_ptr(), dd.data_ptr(), len(k), 40.0,
                               0.08, ur.data_ptr(), dep.data_ptr())
+
+
+@pytest.mark.parametrize("k,L,irregular,levelsup", [(10, 4, False, 2), (10, 3, False, 4), (7, 5, True, 3), (2, 8, True, 0)])
+def test_bow_descend_matches_oracle(k, L, irregular, levelsup):
+    """N2: the DBoW2 tree descent (TemplatedVocabulary.h:1218-1259) per feature; leaf and level node bit-exact."""
+    co, ci, nd, wi, w = synth.random_vocabulary(k, L, 1000 + k * L, irregular=irregular)
+    n = 5000
+    f = synth.random_descriptors(n, 55 + k)
+    f[:500] = nd[(np.arange(500) * 7) % len(nd)]              # features that sit exactly on nodes (ties between duplicates)
+    ref_leaf, ref_nid = O.bow_descend(co, ci, nd, L, f, levelsup)
+    voc = capi.Vocabulary(co, ci, nd, L)
+    m = capi.ORBmatcher()
+    df = _dev(f)
+    leaf = torch.zeros(n, dtype=torch.int32, device="cuda")
+    nid = torch.zeros(n, dtype=torch.int32, device="cuda")
+    m.bow_transform_device(voc, df.data_ptr(), n, levelsup, leaf.data_ptr(), nid.data_ptr())
+    assert np.array_equal(leaf.cpu().numpy(), ref_leaf)
+    assert np.array_equal(nid.cpu().numpy(), ref_nid)
+    assert len(np.unique(ref_leaf)) > 20                       # the features really spread over the tree
+
+
+def test_bow_vocab_argument_errors():
+    co, ci, nd, wi, w = synth.random_vocabulary(3, 2, 5)
+    bad = ci.copy()
+    bad[0] = 0                                                 # a child pointing back at the root: walks would not end
+    with pytest.raises(capi.OrbfeError):
+        capi.Vocabulary(co, bad, nd, 2)
+    voc = capi.Vocabulary(co, ci, nd, 2)
+    m = capi.ORBmatcher()
+    out = torch.zeros(4, dtype=torch.int32, device="cuda")
+    m.bow_transform_device(voc, 0, 0, 1, out.data_ptr(), out.data_ptr())   # no features: nothing to do
+    with pytest.raises(capi.OrbfeError):
+        m.bow_transform_device(voc, 0, 4, 1, out.data_ptr(), out.data_ptr())

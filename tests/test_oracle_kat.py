@@ -515,3 +515,73 @@ def test_stereo_full_vs_numpy_and_geometry():
     assert np.allclose(dep[ok], np.float32(bf) / disp, rtol=1e-6)
     assert (disp > 0).all() and (disp < 62 * 1.2 ** 7).all()
     assert np.all((ur == -1) == (dep == -1))
+
+
+# ---- DBoW2 transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259) ----------------------------------------
+def _tiny_vocab():
+    """root -> A (all 0x00), B (all 0xFF); A -> A0 (0x00), A1 (0x0F);  B -> B0 (0xFF), B1 (0xFF: duplicate), B2 (0xF0)."""
+    desc = np.zeros((8, 32), np.uint8)
+    desc[2], desc[5], desc[6] = 0xFF, 0xFF, 0xFF
+    desc[4], desc[7] = 0x0F, 0xF0
+    child_off = np.array([0, 2, 4, 7, 7, 7, 7, 7, 7], np.int32)
+    child_idx = np.array([1, 2, 3, 4, 5, 6, 7], np.int32)
+    word_id = np.array([-1, -1, -1, 0, 1, 2, 3, 4], np.int32)
+    weight = np.array([0, 0, 0, 1.0, 2.0, 4.0, 8.0, 0.0])       # word 4 (node 7) is stopped
+    return child_off, child_idx, desc, word_id, weight
+
+
+def test_bow_descend_hand_tree():
+    co, ci, nd, wi, w = _tiny_vocab()
+    f = np.zeros((5, 32), np.uint8)
+    f[1] = 0x0F          # nearer to A (128) than to B (128)?  equal: 128 vs 128 -> the first child (A) wins, then A1 exactly
+    f[2] = 0xFF          # B, then B0 and B1 tie at 0: the first (node 5) wins
+    f[3] = 0xF0          # tie at the root -> A; inside A: A0 = 128, A1 = 256 -> A0
+    f[4] = 0xFE          # B (32 vs 224); B0/B1 at 32, B2 at 96 -> node 5
+    leaf, nid = O.bow_descend(co, ci, nd, 2, f, 1)
+    assert leaf.tolist() == [3, 4, 5, 3, 5]
+    assert nid.tolist() == [1, 1, 2, 1, 2]                      # level L - levelsup = 1
+    _, nid0 = O.bow_descend(co, ci, nd, 2, f, 0)
+    assert nid0.tolist() == leaf.tolist()                       # levelsup 0: the leaf itself
+    _, nid2 = O.bow_descend(co, ci, nd, 2, f, 2)
+    assert nid2.tolist() == [0] * 5                             # level <= 0: the root (:1227)
+
+
+def test_bow_transform_weights_and_feature_vector():
+    co, ci, nd, wi, w = _tiny_vocab()
+    f = np.zeros((6, 32), np.uint8)
+    f[1], f[2], f[3], f[4], f[5] = 0x0F, 0xFF, 0xFF, 0xF0 | 0x00, 0xF1
+    f[5] = np.uint8(0xF0)                                       # descends root tie -> A -> A0
+    f[4, :] = 0xFF
+    f[4, :20] = 0xF0                                            # B side, nearest B2 (stopped word)
+    leaf, _ = O.bow_descend(co, ci, nd, 2, f, 1)
+    assert leaf.tolist() == [3, 4, 5, 5, 7, 3]
+    # TF_IDF + L1: word 0 twice (1+1), word 1 once (2), word 2 twice (4+4); word 4 stopped -> dropped from both vectors
+    (ids, vals), (fn, ff) = O.bow_transform(co, ci, nd, wi, w, 2, 0, 1, f, 1)
+    assert ids.tolist() == [0, 1, 2]
+    assert np.array_equal(vals, np.array([2.0, 2.0, 8.0]) / 12.0)
+    assert fn.tolist() == [1, 1, 1, 2, 2] and ff.tolist() == [0, 1, 5, 2, 3]
+    # TF without normalisation divides by the number of words (:1160-1166); BINARY keeps the first weight
+    (_, v_tf), _ = O.bow_transform(co, ci, nd, wi, w, 2, 1, 0, f, 1)
+    assert np.array_equal(v_tf, np.array([2.0, 2.0, 8.0]) / 3.0)
+    (_, v_bin), _ = O.bow_transform(co, ci, nd, wi, w, 2, 3, 0, f, 1)
+    assert np.array_equal(v_bin, np.array([1.0, 2.0, 4.0]))
+    (_, v_l2), _ = O.bow_transform(co, ci, nd, wi, w, 2, 0, 2, f, 1)
+    assert np.allclose(v_l2, np.array([2.0, 2.0, 8.0]) / np.sqrt(72.0), rtol=1e-15)
+
+
+def test_bow_descend_vs_numpy_random_tree():
+    co, ci, nd, wi, w = synth.random_vocabulary(5, 4, 123, irregular=True)
+    f = synth.random_descriptors(300, 77)
+    f[:100] = nd[np.arange(100) * 3 % len(nd)]                  # some features equal to node descriptors
+    leaf, nid = O.bow_descend(co, ci, nd, 4, f, 2)
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for i in range(len(f)):
+        node, level, nn = 0, 0, 0
+        while co[node + 1] > co[node]:
+            level += 1
+            ch = ci[co[node]:co[node + 1]]
+            d = pop[nd[ch] ^ f[i]].sum(axis=1)
+            node = int(ch[int(np.argmin(d))])                   # argmin: the first minimum
+            if level == 4 - 2:
+                nn = node
+        assert leaf[i] == node and nid[i] == nn
