@@ -196,6 +196,13 @@ int orbfe_vocab_destroy(orbfe_vocab *v);
  * that level, where the reference leaves the value unset).  FORB::distance, strict '<': the first minimum wins. */
 int orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocab *v, const uint8_t *dev_desc, int n, int levelsup,
                         int32_t *dev_leaf_node, int32_t *dev_nid, int sync);
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307) for many map points in one call: point p owns the
+ * descriptor rows dev_off[p] .. dev_off[p+1] of dev_desc (the rows of its observations, in the reference's
+ * std::map<KeyFrame*, size_t> iteration order); dev_best[p] = index inside the point of the descriptor with the least
+ * median Hamming distance to the others (median = sorted row [(int)(0.5*(N-1))], the self distance 0 included; the first
+ * minimum wins), -1 for a point without descriptors.  max_per_point = the largest row count (<= 65535). */
+int orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *dev_desc, const int32_t *dev_off, int n_points,
+                                  int max_per_point, int32_t *dev_best, int sync);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

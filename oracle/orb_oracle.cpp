@@ -988,6 +988,32 @@ void orc_bow_transform(const int32_t *child_off, const int32_t *child_idx, const
     *n_fv = k;
 }
 
+/* ------------------------------------------------------------ MapPoint::ComputeDistinctiveDescriptors */
+void orc_distinctive(const uint8_t *desc, const int32_t *off, int n_points, int32_t *best) {
+    for (int p = 0; p < n_points; p++) {
+        const int N = off[p + 1] - off[p];
+        if (N <= 0) { best[p] = -1; continue; }   /* src/MapPoint.cc:257-258, 270-271 */
+        const uint8_t *d = desc + (size_t)off[p] * 32;
+        std::vector<float> D((size_t)N * N);       /* float Distances[N][N], :276 */
+        for (int i = 0; i < N; i++) {
+            D[(size_t)i * N + i] = 0;
+            for (int j = i + 1; j < N; j++) {
+                const int dij = hamming(d + (size_t)i * 32, d + (size_t)j * 32);
+                D[(size_t)i * N + j] = (float)dij;
+                D[(size_t)j * N + i] = (float)dij;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;     /* :289-302 */
+        for (int i = 0; i < N; i++) {
+            std::vector<int> vDists(D.begin() + (size_t)i * N, D.begin() + (size_t)(i + 1) * N);
+            std::sort(vDists.begin(), vDists.end());
+            const int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best[p] = BestIdx;
+    }
+}
+
 /* ------------------------------------------------------------ CPU baseline */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps) {

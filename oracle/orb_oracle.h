@@ -102,6 +102,12 @@ void orc_bow_transform(const int32_t *child_off, const int32_t *child_idx, const
                        const double *weight, int L, int weighting, int norm, const uint8_t *desc, int n, int levelsup,
                        int32_t *bow_ids, double *bow_vals, int32_t *n_bow, int32_t *fv_node, int32_t *fv_feat, int32_t *n_fv);
 
+/* ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched over map points ----
+ * point p owns descriptors desc[off[p] .. off[p+1]); best[p] = index (inside the point) of the descriptor with the least
+ * median distance to the others, median = sorted row[(int)(0.5*(N-1))] with the self distance 0 in the row; first minimum
+ * wins (strict '<' from INT_MAX); -1 for a point without descriptors (the reference returns early). */
+void orc_distinctive(const uint8_t *desc, const int32_t *off, int n_points, int32_t *best);
+
 /* time n_frames calls of orc_extract over `threads` threads (one frame per thread at a time); returns seconds */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps);

@@ -28,7 +28,7 @@ EXPORTS = [
     "orbfe_hamming", "orbfe_matcher_create", "orbfe_matcher_destroy", "orbfe_match_knn2", "orbfe_match_csr",
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
-    "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform",
+    "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -91,6 +91,7 @@ def lib():
     L.orbfe_vocab_create.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.POINTER(vp)]
     L.orbfe_vocab_destroy.argtypes = [vp]
     L.orbfe_bow_transform.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.orbfe_distinctive_descriptors.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int]
     L.orbfe_matcher_synchronize.argtypes = [vp]
     L.orbfe_matcher_stream.restype = vp
     L.orbfe_matcher_stream.argtypes = [vp]
@@ -291,6 +292,10 @@ class ORBmatcher:
     def bow_transform_device(self, vocab: "Vocabulary", desc_ptr, n, levelsup, leaf_ptr, nid_ptr, sync=True):
         check(self._L.orbfe_bow_transform(self._h, vocab._h, vp(desc_ptr), n, levelsup, vp(leaf_ptr), vp(nid_ptr),
                                           1 if sync else 0))
+
+    def distinctive_device(self, desc_ptr, off_ptr, n_points, max_per_point, best_ptr, sync=True):
+        check(self._L.orbfe_distinctive_descriptors(self._h, vp(desc_ptr), vp(off_ptr), n_points, max_per_point, vp(best_ptr),
+                                                    1 if sync else 0))
 
     def synchronize(self):
         check(self._L.orbfe_matcher_synchronize(self._h))

@@ -424,4 +424,49 @@ __global__ __launch_bounds__(256) void bow_descend_kernel(BowArgs a) {
     a.nid[i] = nid;
 }
 
+// ---- MapPoint::ComputeDistinctiveDescriptors, batched (N4) ---------------------------------------------------------
+// Replaces src/MapPoint.cc:273-302 for many map points at once.  One wavefront per map point; lane i owns descriptor i
+// (N <= 64: the common case, a point is seen from a few dozen keyframes), the N x N distance matrix goes to LDS as
+// bytes pairs, the element of rank (int)(0.5*(N-1)) of row i (self distance 0 included) is found by bisection on the
+// value range 0..256 (9 counting passes over the row), then a wave-wide arg-min with the lowest index winning.  Points
+// with more than 64 descriptors walk the rows in blocks of 64 lanes and recompute distances instead of storing them.
+__global__ __launch_bounds__(64) void distinctive_kernel(const uint4 *__restrict__ desc, const int32_t *__restrict__ off, int nPoints,
+                                                         int32_t *__restrict__ best) {
+    __shared__ uint16_t sD[64][64 + 2];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= nPoints) return;
+    const int o0 = off[p], N = off[p + 1] - o0;
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const uint4 *d = desc + 2 * (size_t)o0;
+    const int r = (int)(0.5 * (N - 1));
+    unsigned bestKey = 0xFFFFFFFFu;   // (median << 16 | index): the minimum is the least median, lowest index first
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < N;
+        const uint4 a0 = d[2 * (size_t)min(i, N - 1)], a1 = d[2 * (size_t)min(i, N - 1) + 1];
+        auto dist_to = [&](int j) {
+            const uint4 b0 = d[2 * (size_t)j], b1 = d[2 * (size_t)j + 1];   // wave-uniform j: scalar loads
+            return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                   __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+        };
+        const bool small = N <= 64;
+        if (small)
+            for (int j = 0; j < N; j++) sD[lane][j] = (uint16_t)dist_to(j);   // row i = lane; d(i,i) = 0 by construction
+        // bisection: the smallest v with #{j : d_ij <= v} >= r + 1
+        int lo = 0, hi = 256;
+        while (lo < hi) {   // wave-uniform bounds are not needed: every lane runs 9 steps at most
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            if (small) for (int j = 0; j < N; j++) cnt += sD[lane][j] <= mid ? 1 : 0;
+            else for (int j = 0; j < N; j++) cnt += dist_to(j) <= mid ? 1 : 0;
+            if (cnt >= r + 1) hi = mid; else lo = mid + 1;
+        }
+        const unsigned key = live ? (((unsigned)lo << 16) | (unsigned)i) : 0xFFFFFFFFu;
+        bestKey = min(bestKey, key);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bestKey = min(bestKey, (unsigned)__shfl_xor((int)bestKey, o));
+    if (lane == 0) best[p] = (int)(bestKey & 0xFFFFu);
+}
+
 }  // namespace orbfe

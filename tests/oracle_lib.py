@@ -66,6 +66,8 @@ def lib():
                                          C.c_float, i32p, i32p]
         L.orc_stereo_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u8p, C.c_int, C.c_void_p, u8p, C.c_int,
                                       C.c_float, C.c_float, f32p, f32p]
+        L.orc_distinctive.argtypes = [u8p, i32p, C.c_int, i32p]
+        L.orc_distinctive.restype = None
         L.orc_bow_descend.argtypes = [i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p, i32p]
         L.orc_bow_descend.restype = None
         L.orc_bow_transform.argtypes = [i32p, i32p, u8p, i32p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, u8p, C.c_int,
@@ -287,6 +289,14 @@ def bow_transform(child_off, child_idx, node_desc, word_id, weight, L, weighting
                             _ptr(bi, i32p), bv.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nb), _ptr(fn, i32p),
                             _ptr(ff, i32p), C.byref(nf))
     return (bi[:nb.value].copy(), bv[:nb.value].copy()), (fn[:nf.value].copy(), ff[:nf.value].copy())
+
+
+def distinctive(desc, off):
+    d = np.ascontiguousarray(desc, np.uint8)
+    o = np.ascontiguousarray(off, np.int32)
+    best = np.zeros(len(o) - 1, np.int32)
+    lib().orc_distinctive(_ptr(d, u8p), _ptr(o, i32p), len(o) - 1, _ptr(best, i32p))
+    return best
 
 
 def time_extract(frames: np.ndarray, nfeatures, scale_factor, nlevels, ini_th, min_th, threads, reps=1):

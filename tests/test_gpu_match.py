@@ -221,3 +221,27 @@ def test_bow_vocab_argument_errors():
     m.bow_transform_device(voc, 0, 0, 1, out.data_ptr(), out.data_ptr())   # no features: nothing to do
     with pytest.raises(capi.OrbfeError):
         m.bow_transform_device(voc, 0, 4, 1, out.data_ptr(), out.data_ptr())
+
+
+def test_distinctive_descriptors_match_oracle():
+    """N4: batched MapPoint::ComputeDistinctiveDescriptors; includes empty points, single observations, > 64 observations."""
+    rng = np.random.default_rng(17)
+    sizes = np.concatenate([rng.integers(0, 30, 3000), [64, 65, 130, 1, 0, 2]])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = synth.random_descriptors(int(off[-1]), 21)
+    # observations of one map point resemble each other: copies of a base descriptor with a few bits flipped, some identical
+    for p in range(0, len(sizes), 2):
+        if sizes[p] > 1:
+            base = desc[off[p]].copy()
+            for i in range(off[p], off[p + 1]):
+                d = base.copy()
+                for b in rng.integers(0, 256, int(rng.integers(0, 25))):
+                    d[b >> 3] ^= np.uint8(1 << (b & 7))
+                desc[i] = d
+    ref = O.distinctive(desc, off)
+    m = capi.ORBmatcher()
+    dd, do = _dev(desc), _dev(off)
+    best = torch.full((len(sizes),), -7, dtype=torch.int32, device="cuda")
+    m.distinctive_device(dd.data_ptr(), do.data_ptr(), len(sizes), int(sizes.max()), best.data_ptr())
+    assert np.array_equal(best.cpu().numpy(), ref)
+    assert (ref == -1).sum() == (sizes == 0).sum()

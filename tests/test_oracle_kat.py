@@ -585,3 +585,35 @@ def test_bow_descend_vs_numpy_random_tree():
             if level == 4 - 2:
                 nn = node
         assert leaf[i] == node and nid[i] == nn
+
+
+def test_distinctive_descriptor_hand_cases():
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:273-302): least median, self distance in the row, first wins."""
+    z = np.zeros((1, 32), np.uint8)
+    def bits(k):
+        d = np.zeros(32, np.uint8)
+        for b in range(k):
+            d[b >> 3] |= 1 << (b & 7)
+        return d
+    # three collinear descriptors 0, 10 and 30 bits set: rows sorted (0,10,30), (0,10,20), (0,20,30); rank (int)(0.5*2) = 1
+    # -> medians 10, 10, 20: the first of the two minima (index 0) wins
+    p0 = np.stack([bits(0), bits(10), bits(30)])
+    # four descriptors: rank (int)(0.5*3) = 1 -> the second smallest of each row, i.e. the nearest neighbour's distance
+    p1 = np.stack([bits(0), bits(100), bits(104), bits(200)])     # nearest distances: 100, 4, 4, 96 -> index 1
+    p2 = np.stack([bits(7)])                                      # single observation -> itself
+    desc = np.concatenate([p0, p1, p2])
+    off = np.array([0, 3, 7, 8, 8], np.int32)                     # last point: no descriptors
+    assert O.distinctive(desc, off).tolist() == [0, 1, 0, -1]
+    # numpy restatement on random points
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(1, 40, 200)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = synth.random_descriptors(int(off[-1]), 11)
+    desc[5] = desc[6]                                             # duplicates inside a point
+    got = O.distinctive(desc, off)
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for p in range(len(sizes)):
+        d = desc[off[p]:off[p + 1]]
+        D = pop[d[:, None, :] ^ d[None, :, :]].sum(axis=2)
+        med = np.sort(D, axis=1)[:, int(0.5 * (len(d) - 1))]
+        assert got[p] == int(np.argmin(med))
