@@ -170,6 +170,29 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
         const int x = x0 + b;
         ownMask |= (x >= Xs && x < Xe) ? (0xFFu << (8 * b)) : 0u;
     }
+    // record tag: lane | wave-cell (0..7) of each of the lane's 4 pixels << 6, 3 bits each; the row goes to bit 18
+    uint32_t recTag = (uint32_t)lane;
+    {
+        int segCell0 = 0, cellsBefore = 0;
+        for (int sgi = 0; sgi < nSeg; sgi++) {
+            const FastSeg sg = t.seg[sgi];
+            if (lane >= sg.lane0 && lane < sg.lane0 + sg.nLanes) segCell0 = cellsBefore;
+            cellsBefore += sg.nCells;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int rel = x0 + b - Xs;
+            int cis = 0;
+#pragma unroll
+            for (int c = 1; c < kFastMaxCells; c++) cis += rel >= c * L.wCell ? 1 : 0;
+            recTag |= (uint32_t)min(segCell0 + cis, kFastMaxCells - 1) << (6 + 3 * b);
+        }
+    }
+    // bytes of the lane's dword that lie in the same cell as byte 0 (all of them unless a cell edge cuts the dword)
+    uint32_t sameCell = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        sameCell |= (((recTag >> (6 + 3 * b)) & 7) == ((recTag >> 6) & 7)) ? (0xFFu << (8 * b)) : 0u;
     if (lane < 8) sCellMax[wvi][lane] = 0;
     int listCount = 0;   // wave-uniform
     // per-lane cell-edge masks (16-bit lanes of 0xFFFF where the neighbour on that side is inside the pixel's cell)
@@ -201,13 +224,28 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     cur = prev;
     const u16x2 one = as_pk(0x00010001u);
 
-    // a lane whose dword holds a kept score appends one record (kept scores, lane | row << 8); row-major order
+    // a lane whose dword holds a kept score appends one record (kept scores, recTag | row << 18); row-major order
+    // Two horizontally adjacent pixels can both be kept only across a cell edge (NMS does not look over it); a lane with
+    // kept scores on both sides of an edge writes two records, so that a record holds one cell's scores: at most two.
     auto emit_row = [&](uint32_t Pd, int o) {
         const unsigned long long Bm = __ballot(Pd != 0);
         if (Bm != 0) {   // wave-uniform
-            const int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, 0));
-            if (Pd != 0 && pos < kFastListCap) sList[wvi][pos] = make_uint2(Pd, (uint32_t)lane | ((uint32_t)o << 8));
-            listCount += __popcll(Bm);
+            const uint32_t PdA = Pd & sameCell, PdB = Pd & ~sameCell;
+            const unsigned long long Bs = __ballot(PdA != 0 && PdB != 0);
+            int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, 0));
+            if (Bs != 0) {   // wave-uniform, rare
+                pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(Bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bs, 0));
+                if (PdA != 0 && PdB != 0) {
+                    if (pos < kFastListCap) sList[wvi][pos] = make_uint2(PdA, recTag | ((uint32_t)o << 18));
+                    if (pos + 1 < kFastListCap) sList[wvi][pos + 1] = make_uint2(PdB, recTag | ((uint32_t)o << 18));
+                } else if (Pd != 0 && pos < kFastListCap) {
+                    sList[wvi][pos] = make_uint2(Pd, recTag | ((uint32_t)o << 18));
+                }
+                listCount += __popcll(Bm) + __popcll(Bs);
+            } else {
+                if (Pd != 0 && pos < kFastListCap) sList[wvi][pos] = make_uint2(Pd, recTag | ((uint32_t)o << 18));
+                listCount += __popcll(Bm);
+            }
         }
     };
 
@@ -283,61 +321,50 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
         for (int k = 1; k < nSeg; k++) si += (int)recLane >= sSeg[wvi][k].x ? 1 : 0;   // segments are in lane order
         return sSeg[wvi][si];
     };
-    const int wCell = L.wCell;
     // pass A: cell maxima
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         if (i < listCount) {
             const uint2 rec = sList[wvi][i];
-            const int4 sg = rec_seg(rec.y & 63);
-            const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;   // x - Xs of byte 0
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int sv = (rec.x >> (8 * b)) & 0xFF;
-                if (sv) {
-                    const int rel = rel0 + b;
-                    int cis = 0;
-#pragma unroll
-                    for (int c = 1; c < kFastMaxCells; c++) cis += rel >= c * wCell ? 1 : 0;
-                    atomicMax(&sCellMax[wvi][min(sg.y + cis, kFastMaxCells - 1)], sv);
-                }
+                if (sv) atomicMax(&sCellMax[wvi][(rec.y >> (6 + 3 * b)) & 7], sv);
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int thCell[kFastMaxCells], cntCell[kFastMaxCells];
+    int cntCell[kFastMaxCells];
+    uint32_t iniCells = 0;   // bit c: cell c has a survivor above iniTh, so iniTh is its threshold
 #pragma unroll
     for (int c = 0; c < kFastMaxCells; c++) {
-        thCell[c] = (c < nCellsTotal && sCellMax[wvi][c] > a.iniTh) ? a.iniTh : a.minTh;
+        iniCells |= (c < nCellsTotal && sCellMax[wvi][c] > a.iniTh) ? (1u << c) : 0u;
         cntCell[c] = 0;
     }
-    // the wave-cell (0..7, -1 if the byte holds no survivor) of the four bytes of a record
-    auto rec_cells = [&](const uint2 &rec, const int4 &sg, int (&cw)[4]) {
-        const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;
+    // A record holds at most two kept scores (one cell's, never adjacent pixels).  slots(): the candidates of a record as two slots,
+    // (wave-cell, byte) of the first and of the second byte that passes its cell's threshold; cell 15 = none.
+    auto slots = [&](const uint2 &rec, int &c0, int &b0, int &c1, int &b1) {
+        uint32_t pass = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int sv = (rec.x >> (8 * b)) & 0xFF, rel = rel0 + b;
-            int cis = 0;
-#pragma unroll
-            for (int c = 1; c < kFastMaxCells; c++) cis += rel >= c * wCell ? 1 : 0;
-            cw[b] = sv ? min(sg.y + cis, kFastMaxCells - 1) : -1;
+            const int sv = (rec.x >> (8 * b)) & 0xFF, cw = (rec.y >> (6 + 3 * b)) & 7;
+            const int th = (iniCells >> cw) & 1 ? a.iniTh : a.minTh;
+            pass |= sv > th ? (1u << b) : 0u;
         }
+        b0 = pass ? __builtin_ctz(pass) : 0;
+        b1 = pass ? 31 - __builtin_clz(pass) : 0;
+        c0 = pass ? (int)((rec.y >> (6 + 3 * b0)) & 7) : 15;
+        c1 = (pass && b1 != b0) ? (int)((rec.y >> (6 + 3 * b1)) & 7) : 15;
     };
-    // pass B: candidates per cell.  Two bytes of one dword can both be kept (never adjacent ones), possibly in two cells.
+    // pass B: candidates per cell
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
-        const int4 sg = rec_seg(rec.y & 63);
-        int cw[4];
-        rec_cells(rec, sg, cw);
+        int c0, b0, c1, b1;
+        slots(rec, c0, b0, c1, b1);
 #pragma unroll
-        for (int c = 0; c < kFastMaxCells; c++) {
-            int n = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) n += (cw[b] == c && (int)((rec.x >> (8 * b)) & 0xFF) > thCell[c]) ? 1 : 0;
-            cntCell[c] += __popcll(__ballot(n >= 1)) + __popcll(__ballot(n >= 2));
-        }
+        for (int c = 0; c < kFastMaxCells; c++) cntCell[c] += __popcll(__ballot(c0 == c)) + __popcll(__ballot(c1 == c));
     }
     int offCell[kFastMaxCells], total = 0;
 #pragma unroll
@@ -367,38 +394,38 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
-        const int4 sg = rec_seg(rec.y & 63);
-        int cw[4];
-        rec_cells(rec, sg, cw);
-        int pos[4] = {-1, -1, -1, -1};
+        int c0, b0, c1, b1;
+        slots(rec, c0, b0, c1, b1);
+        int pos0 = -1, pos1 = -1;
 #pragma unroll
         for (int c = 0; c < kFastMaxCells; c++) {
-            int n = 0;
-            bool in[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                in[b] = cw[b] == c && (int)((rec.x >> (8 * b)) & 0xFF) > thCell[c];
-                n += in[b] ? 1 : 0;
-            }
-            const unsigned long long B1 = __ballot(n >= 1), B2 = __ballot(n >= 2);
-            int before = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0)) +
-                         __builtin_amdgcn_mbcnt_hi((uint32_t)(B2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B2, 0));
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (in[b]) pos[b] = before++;
-            run[c] += __popcll(B1) + __popcll(B2);
+            const unsigned long long B0 = __ballot(c0 == c), B1 = __ballot(c1 == c);
+            const int before = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
+                               __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0));
+            if (c0 == c) pos0 = before;
+            if (c1 == c) pos1 = before + (c0 == c ? 1 : 0);
+            run[c] += __popcll(B0) + __popcll(B1);
         }
-        const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            if (pos[b] >= 0 && pos[b] < L.candCap) {
-                // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
+        if (pos0 >= 0) {
+            const int4 sg = rec_seg(rec.y & 63);
+            const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;   // x - Xs of byte 0
+            const int yo = (int)(rec.y >> 18) + sg.w;
+            // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
+            if (pos0 < L.candCap) {
                 Cand cnd;
-                cnd.x = (uint16_t)(rel0 + b + sg.z);
-                cnd.y = (uint16_t)((rec.y >> 8) + sg.w);
-                cnd.resp = (uint16_t)(((rec.x >> (8 * b)) & 0xFF) - 1);
+                cnd.x = (uint16_t)(rel0 + b0 + sg.z);
+                cnd.y = (uint16_t)yo;
+                cnd.resp = (uint16_t)(((rec.x >> (8 * b0)) & 0xFF) - 1);
                 cnd.pad = 0;
-                out[pos[b]] = cnd;
+                out[pos0] = cnd;
+            }
+            if (pos1 >= 0 && pos1 < L.candCap) {
+                Cand cnd;
+                cnd.x = (uint16_t)(rel0 + b1 + sg.z);
+                cnd.y = (uint16_t)yo;
+                cnd.resp = (uint16_t)(((rec.x >> (8 * b1)) & 0xFF) - 1);
+                cnd.pad = 0;
+                out[pos1] = cnd;
             }
         }
     }
