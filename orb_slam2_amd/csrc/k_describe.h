@@ -32,11 +32,8 @@ struct DescribeArgs {
     int *counts;             // [F]
     int cap;
     int nFrames, groupsPerFrame;
+    const uint4 *maskTab;    // desc_mask_table(): [4 alignments][2 slots][64 lanes][4 dwords] x (01-mask, (u+18)-weights)
 };
-
-// umax[v] of the reference constructor (src/ORBextractor.cc:454-469) for HALF_PATCH_SIZE = 15; the host re-derives the
-// table with the reference's arithmetic at create time and refuses to run if it differs.
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "pattern31.inc"
@@ -141,6 +138,34 @@ __device__ __forceinline__ gptr_u8 gptr_from(int lo, int hi) {
     return (gptr_u8)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+constexpr int kDescMaskTabU4 = 4 * 2 * 64 * 4 / 2;   // the table in 16-byte units (1024)
+
+// The 31 x 36-byte moment window is fetched as three 16-byte pieces per row, at dwords 0, 4 and 5 of the row (the third
+// overlaps the second so that nothing is read past byte 35; the overlapped dwords get zero masks).  For patch alignment
+// al = (cx - 15) & 3, load item it = lane + 64 * slot (row it / 3, piece it % 3) and dword q of the piece, the table
+// holds for the 4 bytes: 1 where the pixel lies inside the disc (|u| <= umax[|v|]) and u + 18 there, 0 elsewhere.
+inline void desc_mask_table(const int *umax, uint2 *tab) {
+    for (int al = 0; al < 4; al++)
+        for (int slot = 0; slot < 2; slot++)
+            for (int ln = 0; ln < 64; ln++) {
+                const int it = ln + 64 * slot, row = it / 3, ch = it - row * 3, v = row - kHalfPatch;
+                const int dmax = it < kDescMomentItems ? umax[v < 0 ? -v : v] : -1;
+                const int dw0 = ch == 0 ? 0 : ch == 1 ? 4 : 5;
+                for (int q = 0; q < 4; q++) {
+                    const int dc = dw0 + q;
+                    const bool dup = ch == 2 && q < 3;   // dwords 5..7 already belong to piece 1
+                    uint32_t m01 = 0, mU = 0;
+                    for (int b = 0; b < 4; b++) {
+                        const int u = 4 * dc - kHalfPatch - al + b;
+                        const bool ok = !dup && u >= -dmax && u <= dmax;
+                        m01 |= (ok ? 1u : 0u) << (8 * b);
+                        mU |= (ok ? (uint32_t)(u + 18) : 0u) << (8 * b);
+                    }
+                    tab[((al * 2 + slot) * 64 + ln) * 4 + q] = make_uint2(m01, mU);
+                }
+            }
+}
+
 __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     // [alignment][slot][lane][dword]: (01-mask, (u+18)-weights) of the disc for the dwords of the lane's 16-byte load
     __shared__ __align__(16) uint2 sMask[4][2][64][4];
@@ -154,27 +179,11 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     const int grp = (bid >> 3) % a.groupsPerFrame;
     if (f >= a.nFrames) return;   // whole workgroup
 
-    // The 31 x 36-byte moment window is fetched as three 16-byte pieces per row, at dwords 0, 4 and 5 of the row (the
-    // third overlaps the second so that nothing is read past byte 35); the overlapped dwords get zero masks.
-    for (int e = threadIdx.x; e < 4 * 2 * 64; e += 256) {
-        const int al = e >> 7, slot = (e >> 6) & 1, ln = e & 63;
-        const int it = ln + 64 * slot, row = it / 3, ch = it - row * 3, v = row - kHalfPatch;
-        const int dmax = it < kDescMomentItems ? c_umax[v < 0 ? -v : v] : -1;
-        const int dw0 = ch == 0 ? 0 : ch == 1 ? 4 : 5;
+    // the disc's mask / weight table (desc_mask_table below, built once on the host): 16 KB into LDS
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(&sMask[0][0][0][0]);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int dc = dw0 + q;
-            const bool dup = ch == 2 && q < 3;   // dwords 5..7 already belong to piece 1
-            uint32_t m01 = 0, mU = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int u = 4 * dc - kHalfPatch - al + b;
-                const bool ok = !dup && u >= -dmax && u <= dmax;
-                m01 |= (ok ? 1u : 0u) << (8 * b);
-                mU |= (ok ? (uint32_t)(u + 18) : 0u) << (8 * b);
-            }
-            sMask[al][slot][ln][q] = make_uint2(m01, mU);
-        }
+        for (int k = 0; k < kDescMaskTabU4 / 256; k++) dst[threadIdx.x + 256 * k] = a.maskTab[threadIdx.x + 256 * k];
     }
     __syncthreads();
 

@@ -113,7 +113,7 @@ struct orbfe_extractor {
     std::vector<char> rszWide;          // level needs the 12-byte source window (scale factor ~2 and above)
     std::vector<BlurTile> hBlurTiles;
     std::vector<FastTile> hFastTiles;
-    DevBuf dRsz, dBlurTiles, dFastTiles;
+    DevBuf dRsz, dBlurTiles, dFastTiles, dDescMask;
     // per-batch workspace
     DevBuf dPyr, dBlur, dCand, dSel, dSelCount;
     // status word, per-level candidate counts and the cell table share one allocation: one memset per batch zeroes them
@@ -661,6 +661,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.cap = cap;
         const int maxKp = std::min(g.selFrameCap, cap);
         a.nFrames = F;
+        a.maskTab = (const uint4 *)e->dDescMask.p;
         a.groupsPerFrame = (maxKp + kDescKpPerGroup - 1) / kDescKpPerGroup;
         hipLaunchKernelGGL(orient_describe_kernel, dim3((unsigned)a.groupsPerFrame * ((F + 7) / 8 * 8)), dim3(256), 0, st, a);
     }
@@ -721,6 +722,17 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         orbfe_extractor_destroy(e);
         return fail(ORBFE_ERR_DEVICE, std::string("side stream: ") + hipGetErrorString(er));
     }
+    {
+        // the descriptor kernel's disc mask table, from this object's umax (checked above against the reference's values)
+        std::vector<uint2> tab((size_t)kDescMaskTabU4 * 2);
+        desc_mask_table(e->umax.data(), tab.data());
+        er = e->dDescMask.ensure(tab.size() * sizeof(uint2));
+        if (er == hipSuccess) er = hipMemcpy(e->dDescMask.p, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
+        if (er != hipSuccess) {
+            orbfe_extractor_destroy(e);
+            return fail(ORBFE_ERR_DEVICE, std::string("mask table: ") + hipGetErrorString(er));
+        }
+    }
     if (const char *ov = getenv("ORBFE_OVERLAP")) e->overlap = atoi(ov) != 0;
     *out = e;
     return ORBFE_OK;
@@ -768,7 +780,7 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
             if (ev) (void)hipEventDestroy(ev);
         if (p.counts) (void)hipHostFree(p.counts);
     }
-    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
+    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dDescMask, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
         b->release();
     for (PinBuf *b : {&e->hImg, &e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
