@@ -7,6 +7,8 @@
 //   * Frame::ComputeStereoMatches as a whole (src/Frame.cc:466-640), SAD refinement and median gate included:
 //     orbfe::StereoMatcher below -- no host copy of mvImagePyramid is read
 //   * batched best/second-best for the BoW / projection searches: orbfe_match_knn2 / orbfe_match_csr in orbfe.h.
+//   * Frame::GetFeaturesInArea (src/Frame.cc:327-380) + the candidate loop of SearchByProjection(Frame&, vpMapPoints, th)
+//     (src/ORBmatcher.cc:45-129): orbfe::ProjectionSearch below
 // INTEGRATION.md shows the two-line patches.
 #pragma once
 #include <hip/hip_runtime_api.h>
@@ -113,6 +115,102 @@ private:
     orbfe_matcher *m_;
     void *bufs_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t size_[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:45-129) with the
+// window query and the Hamming loop on the device.  build() is called where the reference calls AssignFeaturesToGrid
+// (src/Frame.cc:96/151/205) with the same members; search() takes what the loop reads from each MapPoint that passes
+// :54-58 (mbTrackInView, !isBad()).  All windows are searched in one launch against the associations that exist when the
+// call is made; the loop's own assignments (:123) are then replayed on the host in the reference's order, and a query
+// whose best or second keypoint was taken by an earlier MapPoint of the same call is searched again, alone, against the
+// updated state -- so the outcome is the sequential loop's, association for association.
+struct ProjectedPoint {
+    float projX, projY, projXR;   // mTrackProjX, mTrackProjY, mTrackProjXR
+    int level;                    // mnTrackScaleLevel
+    float viewCos;                // mTrackViewCos
+    const unsigned char *desc;    // GetDescriptor(): 32 bytes
+};
+class ProjectionSearch {
+public:
+    explicit ProjectionSearch(int device = 0) : dev_(device), m_(nullptr), g_(nullptr) { orbfe_matcher_create(device, &m_); }
+    ~ProjectionSearch() {
+        if (g_) orbfe_frame_grid_destroy(g_);
+        orbfe_matcher_destroy(m_);
+    }
+    int build(const std::vector<cv::KeyPoint> &keysUn, const cv::Mat &desc, const std::vector<float> &uRight, float minX, float minY,
+              float gridElementWidthInv, float gridElementHeightInv) {
+        const int n = (int)keysUn.size();
+        std::vector<float> kx(n), ky(n);
+        std::vector<int32_t> oct(n);
+        std::vector<unsigned char> d((size_t)n * 32);
+        for (int i = 0; i < n; i++) {
+            kx[i] = keysUn[i].pt.x;
+            ky[i] = keysUn[i].pt.y;
+            oct[i] = keysUn[i].octave;
+            for (int b = 0; b < 32; b++) d[(size_t)i * 32 + b] = desc.ptr(i)[b];
+        }
+        if (g_) orbfe_frame_grid_destroy(g_);
+        g_ = nullptr;
+        n_ = n;
+        return orbfe_frame_grid_create(dev_, kx.data(), ky.data(), oct.data(), d.data(), uRight.empty() ? nullptr : uRight.data(), n,
+                                       minX, minY, gridElementWidthInv, gridElementHeightInv, &g_);
+    }
+    // occupied[idx] != 0 where F.mvpMapPoints[idx] is set and has Observations() > 0 (:87-89); updated with the keypoints
+    // this call associates (the MapPoints handed to this function are map points, i.e. observed).  matchIdx[i] is the
+    // keypoint MapPoint i was written to (:123) or -1.  Returns a status; *nmatches is the reference's return value.
+    int search(const std::vector<ProjectedPoint> &pts, const std::vector<float> &scaleFactors, float th, float nnRatio,
+               std::vector<unsigned char> &occupied, std::vector<int> &matchIdx, int *nmatches) {
+        const int nq = (int)pts.size();
+        matchIdx.assign(nq, -1);
+        *nmatches = 0;
+        if (nq == 0 || n_ == 0) return ORBFE_OK;
+        if ((int)occupied.size() != n_) return ORBFE_ERR_ARG;
+        const bool bFactor = th != 1.0f;                                       // :49
+        std::vector<orbfe_area_query> q(nq);
+        std::vector<unsigned char> qd((size_t)nq * 32);
+        for (int i = 0; i < nq; i++) {
+            float r = pts[i].viewCos > 0.998 ? 2.5f : 4.0f;                    // RadiusByViewingCos, :131-137
+            if (bFactor) r *= th;
+            const float rs = r * scaleFactors[pts[i].level];                   // :69 and :94
+            q[i].x = pts[i].projX;
+            q[i].y = pts[i].projY;
+            q[i].r = rs;
+            q[i].min_level = pts[i].level - 1;
+            q[i].max_level = pts[i].level;
+            q[i].proj_xr = pts[i].projXR;
+            q[i].er_max = rs;
+            q[i].pad = 0;
+            for (int b = 0; b < 32; b++) qd[(size_t)i * 32 + b] = pts[i].desc[b];
+        }
+        std::vector<orbfe_area_result> res(nq);
+        int rc = orbfe_search_area(m_, g_, q.data(), qd.data(), nq, occupied.data(), res.data());
+        if (rc != ORBFE_OK) return rc;
+        std::vector<unsigned char> taken(n_, 0);                               // associations made by this call
+        for (int i = 0; i < nq; i++) {
+            orbfe_area_result r = res[i];
+            if ((r.best_idx >= 0 && taken[r.best_idx]) || (r.best_idx2 >= 0 && taken[r.best_idx2])) {
+                rc = orbfe_search_area(m_, g_, &q[i], &qd[(size_t)i * 32], 1, occupied.data(), &r);
+                if (rc != ORBFE_OK) return rc;
+                requeried_++;
+            }
+            if (r.best_dist <= 100) {                                          // TH_HIGH, :118
+                if (r.best_level == r.best_level2 && r.best_dist > nnRatio * r.best_dist2) continue;   // :120
+                occupied[r.best_idx] = 1;                                      // :123
+                taken[r.best_idx] = 1;
+                matchIdx[i] = r.best_idx;
+                (*nmatches)++;
+            }
+        }
+        return ORBFE_OK;
+    }
+    long requeried() const { return requeried_; }
+
+private:
+    int dev_;
+    orbfe_matcher *m_;
+    orbfe_frame_grid *g_;
+    int n_ = 0;
+    long requeried_ = 0;
 };
 
 }  // namespace orbfe

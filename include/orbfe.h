@@ -203,6 +203,34 @@ int orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocab *v, const uint8_t *d
  * minimum wins), -1 for a point without descriptors.  max_per_point = the largest row count (<= 65535). */
 int orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *dev_desc, const int32_t *dev_off, int n_points,
                                   int max_per_point, int32_t *dev_best, int sync);
+/* The frame grid and the windowed search on it: Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:230-246, 382-392),
+ * Frame::GetFeaturesInArea (:327-380) and the candidate loop of ORBmatcher::SearchByProjection(Frame&,
+ * const vector<MapPoint*>&, th) (src/ORBmatcher.cc:71-115), for a batch of projected map points.  The grid is built on
+ * the host from the Frame members (undistorted keypoint coordinates and octaves, descriptors, mvuRight or NULL,
+ * mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv) exactly as the reference builds mGrid, and kept on the
+ * device.  Host pointers throughout: these calls sit inside host loops of the reference. */
+typedef struct orbfe_frame_grid orbfe_frame_grid;
+typedef struct orbfe_area_query {
+    float x, y, r;                /* GetFeaturesInArea(x, y, r, min_level, max_level) */
+    int32_t min_level, max_level;
+    float proj_xr, er_max;        /* :87-92: skip idx when mvuRight[idx] > 0 and |proj_xr - mvuRight[idx]| > er_max; off if er_max < 0 */
+    int32_t pad;
+} orbfe_area_query;
+typedef struct orbfe_area_result {
+    int32_t best_dist, best_idx, best_level, best_dist2, best_level2;   /* 256, -1, -1, 256, -1 when nothing was compared */
+    int32_t n_candidates;                                               /* vIndices.size() */
+    int32_t best_idx2;   /* the keypoint that holds best_dist2 / best_level2 (-1 if none): the reference keeps no such local; it
+                          * lets the caller tell whether an association made later in its loop touches this result */
+    int32_t pad1;
+} orbfe_area_result;
+int orbfe_frame_grid_create(int device, const float *kx, const float *ky, const int32_t *koct, const uint8_t *kdesc,
+                            const float *uright, int n, float min_x, float min_y, float width_inv, float height_inv,
+                            orbfe_frame_grid **out);
+int orbfe_frame_grid_destroy(orbfe_frame_grid *g);
+/* blocked (n bytes or NULL): keypoints the loop skips (:83-85: already associated with an observed MapPoint when the call
+ * is made; associations made DURING the reference's loop are the caller's to replay).  Synchronous. */
+int orbfe_search_area(orbfe_matcher *m, orbfe_frame_grid *g, const orbfe_area_query *queries, const uint8_t *query_desc, int nq,
+                      const uint8_t *blocked, orbfe_area_result *results);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

@@ -1014,6 +1014,85 @@ void orc_distinctive(const uint8_t *desc, const int32_t *off, int n_points, int3
     }
 }
 
+/* ------------------------------------------------------------ Frame grid + windowed search */
+struct orc_grid {
+    std::vector<float> kx, ky;
+    std::vector<int32_t> koct;
+    float minX, minY, wInv, hInv;
+    std::vector<int32_t> cell[64][48];   /* mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS] */
+};
+
+orc_grid *orc_grid_create(const float *kx, const float *ky, const int32_t *koct, int n, float min_x, float min_y,
+                          float width_inv, float height_inv) {
+    orc_grid *g = new orc_grid;
+    g->kx.assign(kx, kx + n); g->ky.assign(ky, ky + n); g->koct.assign(koct, koct + n);
+    g->minX = min_x; g->minY = min_y; g->wInv = width_inv; g->hInv = height_inv;
+    for (int i = 0; i < n; i++) {   /* Frame::AssignFeaturesToGrid :230-246, PosInGrid :382-392 */
+        const int posX = (int)std::round((kx[i] - min_x) * width_inv);
+        const int posY = (int)std::round((ky[i] - min_y) * height_inv);
+        if (posX < 0 || posX >= 64 || posY < 0 || posY >= 48) continue;
+        g->cell[posX][posY].push_back(i);
+    }
+    return g;
+}
+
+void orc_grid_destroy(orc_grid *g) { delete g; }
+
+int orc_features_in_area(const orc_grid *g, float x, float y, float r, int minLevel, int maxLevel, int32_t *out) {
+    int n = 0;   /* Frame::GetFeaturesInArea :327-380 */
+    const int nMinCellX = std::max(0, (int)std::floor((x - g->minX - r) * g->wInv));
+    if (nMinCellX >= 64) return 0;
+    const int nMaxCellX = std::min(64 - 1, (int)std::ceil((x - g->minX + r) * g->wInv));
+    if (nMaxCellX < 0) return 0;
+    const int nMinCellY = std::max(0, (int)std::floor((y - g->minY - r) * g->hInv));
+    if (nMinCellY >= 48) return 0;
+    const int nMaxCellY = std::min(48 - 1, (int)std::ceil((y - g->minY + r) * g->hInv));
+    if (nMaxCellY < 0) return 0;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int32_t> &vCell = g->cell[ix][iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+                const int idx = vCell[j];
+                if (bCheckLevels) {
+                    if (g->koct[idx] < minLevel) continue;
+                    if (maxLevel >= 0 && g->koct[idx] > maxLevel) continue;
+                }
+                const float distx = g->kx[idx] - x, disty = g->ky[idx] - y;
+                if (std::fabs(distx) < r && std::fabs(disty) < r) out[n++] = idx;
+            }
+        }
+    return n;
+}
+
+void orc_search_area(const orc_grid *g, const uint8_t *kdesc, const float *uright, const uint8_t *blocked, float x, float y,
+                     float r, int minLevel, int maxLevel, float projXR, float erMax, const uint8_t *qdesc, int32_t res[7]) {
+    std::vector<int32_t> vIndices(g->kx.size() + 1);
+    const int n = orc_features_in_area(g, x, y, r, minLevel, maxLevel, vIndices.data());
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;   /* src/ORBmatcher.cc:71-75 */
+    int bestIdx2 = -1;   /* bookkeeping the reference does not keep: which keypoint holds bestDist2 / bestLevel2 */
+    for (int k = 0; k < n; k++) {
+        const int idx = vIndices[k];
+        if (blocked && blocked[idx]) continue;                                    /* :83-85 */
+        if (erMax >= 0 && uright && uright[idx] > 0) {                            /* :87-92 */
+            const float er = std::fabs(projXR - uright[idx]);
+            if (er > erMax) continue;
+        }
+        const int dist = hamming(qdesc, kdesc + (size_t)idx * 32);
+        if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = g->koct[idx];
+            bestIdx2 = bestIdx; bestIdx = idx;
+        } else if (dist < bestDist2) {
+            bestLevel2 = g->koct[idx];
+            bestDist2 = dist;
+            bestIdx2 = idx;
+        }
+    }
+    res[0] = bestDist; res[1] = bestIdx; res[2] = bestLevel; res[3] = bestDist2; res[4] = bestLevel2; res[5] = n;
+    res[6] = bestIdx2;
+}
+
 /* ------------------------------------------------------------ CPU baseline */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps) {

@@ -108,6 +108,21 @@ void orc_bow_transform(const int32_t *child_off, const int32_t *child_idx, const
  * wins (strict '<' from INT_MAX); -1 for a point without descriptors (the reference returns early). */
 void orc_distinctive(const uint8_t *desc, const int32_t *off, int n_points, int32_t *best);
 
+/* ---- Frame grid (src/Frame.cc:230-246, 327-392) and the windowed best/second search of SearchByProjection ----
+ * keypoints: kx, ky (undistorted coordinates), koct (octave).  Grid: 64 x 48 cells (include/Frame.h:37-38). */
+typedef struct orc_grid orc_grid;
+orc_grid *orc_grid_create(const float *kx, const float *ky, const int32_t *koct, int n, float min_x, float min_y,
+                          float width_inv, float height_inv);
+void orc_grid_destroy(orc_grid *g);
+/* Frame::GetFeaturesInArea (:327-380): indices in the reference's order; returns the count (out has room for n) */
+int orc_features_in_area(const orc_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out);
+/* the candidate loop of ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:71-115) for one
+ * query: candidates from GetFeaturesInArea, skip blocked[idx] != 0 (:83-85, a static snapshot), the right-coordinate gate
+ * (:87-92) when er_max >= 0, strict '<' best / second with their levels.  res = {bestDist, bestIdx, bestLevel, bestDist2,
+ * bestLevel2, number of candidates returned by GetFeaturesInArea} */
+void orc_search_area(const orc_grid *g, const uint8_t *kdesc, const float *uright, const uint8_t *blocked, float x, float y,
+                     float r, int min_level, int max_level, float proj_xr, float er_max, const uint8_t *qdesc, int32_t res[7]);
+
 /* time n_frames calls of orc_extract over `threads` threads (one frame per thread at a time); returns seconds */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps);

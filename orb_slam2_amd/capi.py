@@ -29,6 +29,7 @@ EXPORTS = [
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
+    "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -92,6 +93,10 @@ def lib():
     L.orbfe_vocab_destroy.argtypes = [vp]
     L.orbfe_bow_transform.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
     L.orbfe_distinctive_descriptors.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int]
+    L.orbfe_frame_grid_create.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.POINTER(vp)]
+    L.orbfe_frame_grid_destroy.argtypes = [vp]
+    L.orbfe_search_area.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.orbfe_matcher_synchronize.argtypes = [vp]
     L.orbfe_matcher_stream.restype = vp
     L.orbfe_matcher_stream.argtypes = [vp]
@@ -302,6 +307,47 @@ class ORBmatcher:
 
     def stream(self) -> int:
         return int(self._L.orbfe_matcher_stream(self._h) or 0)
+
+
+AREA_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                             ("proj_xr", "<f4"), ("er_max", "<f4"), ("pad", "<i4")])
+AREA_RESULT_DTYPE = np.dtype([("best_dist", "<i4"), ("best_idx", "<i4"), ("best_level", "<i4"), ("best_dist2", "<i4"),
+                              ("best_level2", "<i4"), ("n_candidates", "<i4"), ("best_idx2", "<i4"), ("pad1", "<i4")])
+
+
+class FrameGrid:
+    """Device copy of a Frame's 64 x 48 keypoint grid (include/orbfe.h: orbfe_frame_grid_create) + windowed search."""
+
+    def __init__(self, kx, ky, koct, kdesc, uright, min_x, min_y, width_inv, height_inv, device=0):
+        self._L = lib()
+        self._h = vp()
+        kx, ky = np.ascontiguousarray(kx, np.float32), np.ascontiguousarray(ky, np.float32)
+        koct, kdesc = np.ascontiguousarray(koct, np.int32), np.ascontiguousarray(kdesc, np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        self.n = len(kx)
+        check(self._L.orbfe_frame_grid_create(device, _np_ptr(kx), _np_ptr(ky), _np_ptr(koct), _np_ptr(kdesc),
+                                              None if ur is None else _np_ptr(ur), self.n, min_x, min_y, width_inv, height_inv,
+                                              C.byref(self._h)))
+
+    def search(self, matcher: "ORBmatcher", queries: np.ndarray, qdesc: np.ndarray, blocked=None) -> np.ndarray:
+        q = np.ascontiguousarray(queries, AREA_QUERY_DTYPE)
+        d = np.ascontiguousarray(qdesc, np.uint8)
+        b = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+        res = np.zeros(len(q), AREA_RESULT_DTYPE)
+        check(self._L.orbfe_search_area(matcher._h, self._h, _np_ptr(q), _np_ptr(d), len(q), None if b is None else _np_ptr(b),
+                                        _np_ptr(res)))
+        return res
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbfe_frame_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Vocabulary:

@@ -469,4 +469,85 @@ __global__ __launch_bounds__(64) void distinctive_kernel(const uint4 *__restrict
     if (lane == 0) best[p] = (int)(bestKey & 0xFFFFu);
 }
 
+// ---- windowed search on the frame grid (rest of N4) -----------------------------------------------------------------
+// Replaces Frame::GetFeaturesInArea (reference src/Frame.cc:327-380) plus the candidate loop of
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:71-115) for a batch of
+// projected map points.  The grid (64 x 48 cells, cell lists in keypoint order as Frame::AssignFeaturesToGrid builds them)
+// lives on the device as a CSR; one query per lane walks its cells in the reference's order (ix outer, iy inner, list
+// order inside a cell) and keeps best / second with the reference's strict '<' updates, so ties resolve identically.
+struct AreaQuery {       // == orbfe_area_query
+    float x, y, r;       // mTrackProjX, mTrackProjY, radius
+    int minLevel, maxLevel;
+    float projXR, erMax; // right-coordinate gate (:87-92), off when erMax < 0
+    int pad;
+};
+struct AreaResult {      // == orbfe_area_result
+    int bestDist, bestIdx, bestLevel, bestDist2, bestLevel2, nCand, bestIdx2, pad1;
+};
+struct AreaArgs {
+    const int32_t *cellOff;      // [64*48 + 1], cell id = ix * 48 + iy
+    const int32_t *cellIdx;
+    const float *kx, *ky;
+    const int32_t *koct;
+    const uint4 *kdesc;          // [n][2]
+    const float *uRight;         // may be null
+    const uint8_t *blocked;      // may be null
+    float minX, minY, wInv, hInv;
+    const AreaQuery *q;
+    const uint4 *qdesc;          // [nq][2]
+    int nq;
+    AreaResult *res;
+};
+
+__global__ __launch_bounds__(256) void search_area_kernel(AreaArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nq) return;
+    const AreaQuery q = a.q[i];
+    AreaResult out;
+    out.bestDist = 256; out.bestIdx = -1; out.bestLevel = -1; out.bestDist2 = 256; out.bestLevel2 = -1; out.nCand = 0;
+    out.bestIdx2 = -1; out.pad1 = 0;
+    // :332-346, float operations in the reference's order
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.x, a.minX), q.r), a.wInv)));
+    const int nMaxCellX = min(64 - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.x, a.minX), q.r), a.wInv)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(q.y, a.minY), q.r), a.hInv)));
+    const int nMaxCellY = min(48 - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(q.y, a.minY), q.r), a.hInv)));
+    if (!(nMinCellX >= 64 || nMaxCellX < 0 || nMinCellY >= 48 || nMaxCellY < 0)) {
+        const uint4 q0 = a.qdesc[2 * (size_t)i], q1 = a.qdesc[2 * (size_t)i + 1];
+        const bool bCheckLevels = q.minLevel > 0 || q.maxLevel >= 0;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const int c0 = a.cellOff[ix * 48 + iy], c1 = a.cellOff[ix * 48 + iy + 1];
+                for (int c = c0; c < c1; c++) {
+                    const int idx = a.cellIdx[c];
+                    const int oct = a.koct[idx];
+                    if (bCheckLevels) {
+                        if (oct < q.minLevel) continue;
+                        if (q.maxLevel >= 0 && oct > q.maxLevel) continue;
+                    }
+                    const float distx = __fsub_rn(a.kx[idx], q.x), disty = __fsub_rn(a.ky[idx], q.y);
+                    if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) continue;
+                    out.nCand++;                                        // an element of vIndices
+                    if (a.blocked && a.blocked[idx]) continue;          // src/ORBmatcher.cc:83-85
+                    if (q.erMax >= 0 && a.uRight) {                     // :87-92
+                        const float ur = a.uRight[idx];
+                        if (ur > 0 && fabsf(__fsub_rn(q.projXR, ur)) > q.erMax) continue;
+                    }
+                    const uint4 d0 = a.kdesc[2 * (size_t)idx], d1 = a.kdesc[2 * (size_t)idx + 1];
+                    const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                                     __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+                    if (dist < out.bestDist) {                          // :100-113
+                        out.bestDist2 = out.bestDist; out.bestDist = dist;
+                        out.bestLevel2 = out.bestLevel; out.bestLevel = oct;
+                        out.bestIdx2 = out.bestIdx; out.bestIdx = idx;
+                    } else if (dist < out.bestDist2) {
+                        out.bestLevel2 = oct;
+                        out.bestDist2 = dist;
+                        out.bestIdx2 = idx;
+                    }
+                }
+            }
+    }
+    a.res[i] = out;
+}
+
 }  // namespace orbfe

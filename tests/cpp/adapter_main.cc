@@ -3,6 +3,9 @@
 // pytest driver can compare them with the oracle.  usage: adapter_main in.raw w h nfeatures out.bin
 //                                                          adapter_main stereo left.raw right.raw w h nfeatures bf b out.bin
 //                                                          adapter_main bow voc.txt desc.raw n levelsup out.bin
+//                                                          adapter_main project case.bin out.bin
+// The project mode replays ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (src/ORBmatcher.cc:45-129) on a frame
+// and a list of projected map points read from case.bin (layout in tests/test_gpu_adapter.py).
 // The bow mode loads a vocabulary in the ORBvoc.txt format and runs Frame::ComputeBoW's transform (src/Frame.cc:395-402).
 // The stereo mode follows the Frame stereo constructor (src/Frame.cc:59-93): two extractors, then ComputeStereoMatches.
 #include <cstdio>
@@ -76,7 +79,52 @@ static int bow_main(char **argv) {
     return 0;
 }
 
+static int project_main(char **argv) {
+    FILE *fi = std::fopen(argv[2], "rb");
+    if (!fi) return 3;
+    int n = 0, nq = 0, nl = 0;
+    float f[6];
+    bool ok = std::fread(&n, 4, 1, fi) == 1 && std::fread(&nq, 4, 1, fi) == 1 && std::fread(f, 4, 6, fi) == 6 &&
+              std::fread(&nl, 4, 1, fi) == 1;
+    if (!ok || n < 0 || nq < 0 || nl < 1 || nl > 64) return 3;
+    std::vector<float> sf(nl), kx(n), ky(n), ur(n), px(nq), py(nq), pxr(nq), vc(nq);
+    std::vector<int> oct(n), lvl(nq);
+    std::vector<unsigned char> desc((size_t)n * 32 + 1), occ(n), qd((size_t)nq * 32 + 1);
+    auto rd = [&](void *p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, fi) == bytes; };
+    ok = rd(sf.data(), 4 * (size_t)nl) && rd(kx.data(), 4 * (size_t)n) && rd(ky.data(), 4 * (size_t)n) && rd(oct.data(), 4 * (size_t)n) &&
+         rd(ur.data(), 4 * (size_t)n) && rd(desc.data(), 32 * (size_t)n) && rd(occ.data(), (size_t)n) && rd(px.data(), 4 * (size_t)nq) &&
+         rd(py.data(), 4 * (size_t)nq) && rd(pxr.data(), 4 * (size_t)nq) && rd(lvl.data(), 4 * (size_t)nq) && rd(vc.data(), 4 * (size_t)nq) &&
+         rd(qd.data(), 32 * (size_t)nq);
+    std::fclose(fi);
+    if (!ok) return 3;
+    std::vector<cv::KeyPoint> keys(n);
+    for (int i = 0; i < n; i++) {
+        keys[i].pt.x = kx[i];
+        keys[i].pt.y = ky[i];
+        keys[i].octave = oct[i];
+    }
+    cv::Mat D(n, 32, CV_8UC1, desc.data(), (size_t)32);
+    orbfe::ProjectionSearch ps;
+    if (ps.build(keys, D, ur, f[0], f[1], f[2], f[3]) != 0) { std::fprintf(stderr, "project: %s\n", orbfe_last_error()); return 5; }
+    std::vector<orbfe::ProjectedPoint> pts(nq);
+    for (int i = 0; i < nq; i++) pts[i] = {px[i], py[i], pxr[i], lvl[i], vc[i], qd.data() + (size_t)i * 32};
+    std::vector<int> matchIdx;
+    int nmatches = 0;
+    if (ps.search(pts, sf, f[4], f[5], occ, matchIdx, &nmatches) != 0) { std::fprintf(stderr, "project: %s\n", orbfe_last_error()); return 6; }
+    FILE *fo = std::fopen(argv[3], "wb");
+    if (!fo) return 4;
+    const int rq = (int)ps.requeried();
+    std::fwrite(&nmatches, 4, 1, fo);
+    std::fwrite(&rq, 4, 1, fo);
+    std::fwrite(matchIdx.data(), 4, nq, fo);
+    std::fwrite(occ.data(), 1, n, fo);
+    std::fclose(fo);
+    std::printf("adapter project ok: %d map points, %d matches, %d searched again\n", nq, nmatches, rq);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 4 && std::strcmp(argv[1], "project") == 0) return project_main(argv);
     if (argc >= 7 && std::strcmp(argv[1], "bow") == 0) return bow_main(argv);
     if (argc >= 10 && std::strcmp(argv[1], "stereo") == 0) return stereo_main(argv);
     if (argc < 6) return 2;

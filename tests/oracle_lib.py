@@ -66,6 +66,14 @@ def lib():
                                          C.c_float, i32p, i32p]
         L.orc_stereo_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u8p, C.c_int, C.c_void_p, u8p, C.c_int,
                                       C.c_float, C.c_float, f32p, f32p]
+        L.orc_grid_create.restype = C.c_void_p
+        L.orc_grid_create.argtypes = [f32p, f32p, i32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_grid_destroy.argtypes = [C.c_void_p]
+        L.orc_grid_destroy.restype = None
+        L.orc_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, i32p]
+        L.orc_search_area.argtypes = [C.c_void_p, u8p, f32p, u8p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
+                                      C.c_float, u8p, i32p]
+        L.orc_search_area.restype = None
         L.orc_distinctive.argtypes = [u8p, i32p, C.c_int, i32p]
         L.orc_distinctive.restype = None
         L.orc_bow_descend.argtypes = [i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p, i32p]
@@ -297,6 +305,36 @@ def distinctive(desc, off):
     best = np.zeros(len(o) - 1, np.int32)
     lib().orc_distinctive(_ptr(d, u8p), _ptr(o, i32p), len(o) - 1, _ptr(best, i32p))
     return best
+
+
+class OracleGrid:
+    """Frame::AssignFeaturesToGrid + GetFeaturesInArea + the SearchByProjection candidate loop on the oracle."""
+
+    def __init__(self, kx, ky, koct, kdesc, uright, min_x, min_y, width_inv, height_inv):
+        self.kx, self.ky = np.ascontiguousarray(kx, np.float32), np.ascontiguousarray(ky, np.float32)
+        self.koct, self.kdesc = np.ascontiguousarray(koct, np.int32), np.ascontiguousarray(kdesc, np.uint8)
+        self.uright = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        self.h = lib().orc_grid_create(_ptr(self.kx, f32p), _ptr(self.ky, f32p), _ptr(self.koct, i32p), len(self.kx), min_x, min_y,
+                                       width_inv, height_inv)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_grid_destroy(self.h)
+            self.h = None
+
+    def features_in_area(self, x, y, r, min_level, max_level):
+        out = np.zeros(len(self.kx) + 1, np.int32)
+        n = lib().orc_features_in_area(self.h, x, y, r, min_level, max_level, _ptr(out, i32p))
+        return out[:n].copy()
+
+    def search(self, x, y, r, min_level, max_level, proj_xr, er_max, qdesc, blocked=None):
+        res = np.zeros(7, np.int32)
+        q = np.ascontiguousarray(qdesc, np.uint8)
+        b = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+        lib().orc_search_area(self.h, _ptr(self.kdesc, u8p), None if self.uright is None else _ptr(self.uright, f32p),
+                              None if b is None else _ptr(b, u8p), x, y, r, min_level, max_level, proj_xr, er_max, _ptr(q, u8p),
+                              _ptr(res, i32p))
+        return res
 
 
 def time_extract(frames: np.ndarray, nfeatures, scale_factor, nlevels, ini_th, min_th, threads, reps=1):

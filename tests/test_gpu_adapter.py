@@ -96,3 +96,69 @@ def test_cpp_vocabulary_transform_matches_oracle(tmp_path):
     assert np.array_equal(vals.view(np.uint64), rvals.view(np.uint64))  # bit-exact doubles
     assert np.array_equal(fv[:, 0], rfn) and np.array_equal(fv[:, 1], rff)
     assert abs(vals.sum() - 1.0) < 1e-12                                # L1-normalised
+
+
+def test_cpp_projection_search_replays_the_reference_loop(tmp_path):
+    """orbfe::ProjectionSearch (include/ORBmatcher_orbfe.h) == ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th)
+    (src/ORBmatcher.cc:45-129) run sequentially on the oracle: same association per map point, same nmatches, including
+    map points whose best keypoint was taken earlier in the same call (those are searched again on the device)."""
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    assert exe.exists()
+    W, H = 1241, 376
+    img = synth.textured_image(W, H, synth.BASE_SEED + 321)
+    o = O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    k, d = o.extract(img)
+    n = len(k)
+    rng = np.random.default_rng(19)
+    kx, ky, koct = k["x"].copy(), k["y"].copy(), k["octave"].astype(np.int32)
+    ur = np.where(rng.uniform(size=n) < 0.5, kx - rng.uniform(1, 60, n), -1).astype(np.float32)
+    w_inv, h_inv = np.float32(64) / np.float32(W), np.float32(48) / np.float32(H)
+    sf = np.array([np.float32(1.2) ** 0] * 8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * np.float32(1.2)                      # ORBextractor.cc:417-421
+    nq = 2500                                                    # more map points than free keypoints nearby: contention
+    src = rng.integers(0, n, nq)
+    px = (kx[src] + rng.uniform(-3, 3, nq)).astype(np.float32)
+    py = (ky[src] + rng.uniform(-3, 3, nq)).astype(np.float32)
+    pxr = np.where(ur[src] > 0, ur[src] + rng.uniform(-2, 2, nq), px - 20).astype(np.float32)
+    lvl = np.clip(koct[src] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+    vcos = rng.choice([0.9, 0.9995], nq).astype(np.float32)
+    qd = d[src].copy()
+    flip = rng.integers(0, 256, (nq, 10))
+    for i in range(nq):
+        for b in flip[i]:
+            qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    occ = (rng.uniform(size=n) < 0.1).astype(np.uint8)
+    th, nnratio = np.float32(3.0), np.float32(0.8)
+    case, out = tmp_path / "case.bin", tmp_path / "out.bin"
+    with open(case, "wb") as fh:
+        fh.write(np.array([n, nq], np.int32).tobytes())
+        fh.write(np.array([0.0, 0.0, w_inv, h_inv, th, nnratio], np.float32).tobytes())
+        fh.write(np.array([8], np.int32).tobytes())
+        for a in (sf, kx, ky, koct, ur, d, occ, px, py, pxr, lvl, vcos, qd):
+            fh.write(np.ascontiguousarray(a).tobytes())
+    r = subprocess.run([str(exe), "project", str(case), str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    nmatches, requeried = np.frombuffer(buf, np.int32, 2)
+    match_idx = np.frombuffer(buf, np.int32, nq, 8)
+    occ_out = np.frombuffer(buf, np.uint8, n, 8 + 4 * nq)
+    # the reference's loop, one map point after the other, on the oracle
+    og = O.OracleGrid(kx, ky, koct, d, ur, 0.0, 0.0, float(w_inv), float(h_inv))
+    blocked = occ.copy()
+    want = np.full(nq, -1, np.int32)
+    for i in range(nq):
+        rad = np.float32(2.5) if float(vcos[i]) > 0.998 else np.float32(4.0)
+        rad = rad * th
+        rs = float(np.float32(rad * sf[lvl[i]]))
+        res = og.search(float(px[i]), float(py[i]), rs, int(lvl[i]) - 1, int(lvl[i]), float(pxr[i]), rs, qd[i], blocked)
+        if res[5] == 0:
+            continue
+        if res[0] <= 100:
+            if res[2] == res[4] and np.float32(res[0]) > nnratio * np.float32(res[3]):
+                continue
+            want[i] = res[1]
+            blocked[res[1]] = 1
+    assert np.array_equal(match_idx, want)
+    assert nmatches == (want >= 0).sum() and np.array_equal(occ_out, blocked)
+    assert nmatches > 500 and requeried > 10                     # contention really occurred and was replayed

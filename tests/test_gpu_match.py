@@ -245,3 +245,50 @@ def test_distinctive_descriptors_match_oracle():
     m.distinctive_device(dd.data_ptr(), do.data_ptr(), len(sizes), int(sizes.max()), best.data_ptr())
     assert np.array_equal(best.cpu().numpy(), ref)
     assert (ref == -1).sum() == (sizes == 0).sum()
+
+
+def test_search_area_matches_oracle():
+    """Rest of N4: device frame grid + windowed best/second search == GetFeaturesInArea + the SearchByProjection loop."""
+    W, H = 1241, 376
+    img = synth.textured_image(W, H, synth.BASE_SEED + 123)
+    k, d = capi.ORBextractor(2000, 1.2, 8, 20, 7)(img)
+    n = len(k)
+    rng = np.random.default_rng(9)
+    kx, ky, koct = k["x"].copy(), k["y"].copy(), k["octave"].astype(np.int32)
+    ur = np.where(rng.uniform(size=n) < 0.5, kx - rng.uniform(1, 60, n), -1).astype(np.float32)
+    mn_x, mn_y = 0.0, 0.0
+    w_inv, h_inv = float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H))
+    og = O.OracleGrid(kx, ky, koct, d, ur, mn_x, mn_y, w_inv, h_inv)
+    gg = capi.FrameGrid(kx, ky, koct, d, ur, mn_x, mn_y, w_inv, h_inv)
+    m = capi.ORBmatcher()
+    nq = 3000
+    q = np.zeros(nq, capi.AREA_QUERY_DTYPE)
+    src = rng.integers(0, n, nq)
+    q["x"] = kx[src] + rng.uniform(-6, 6, nq)                   # projections near real keypoints (plus some far off)
+    q["y"] = ky[src] + rng.uniform(-6, 6, nq)
+    q["x"][:50] = rng.uniform(-200, W + 200, 50)
+    q["y"][:50] = rng.uniform(-200, H + 200, 50)
+    lvl = koct[src]
+    q["r"] = (rng.choice([2.5, 4.0], nq) * (1.2 ** lvl) * rng.choice([1.0, 3.0], nq)).astype(np.float32)
+    q["min_level"], q["max_level"] = lvl - 1, lvl
+    q["min_level"][100:200], q["max_level"][100:200] = -1, -1   # no level check
+    q["min_level"][200:300], q["max_level"][200:300] = 2, -1    # lower bound only
+    q["proj_xr"] = q["x"] - rng.uniform(1, 60, nq)
+    q["er_max"] = np.where(rng.uniform(size=nq) < 0.5, q["r"], -1).astype(np.float32)
+    qd = synth.planted_queries(d, nq, 77, planted_frac=0.0)
+    qd[:] = d[src]
+    flip = rng.integers(0, 256, (nq, 12))
+    for i in range(nq):
+        for b in flip[i]:
+            qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    blocked = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    for use_blocked in (False, True):
+        res = gg.search(m, q, qd, blocked if use_blocked else None)
+        for i in range(nq):
+            ref = og.search(float(q["x"][i]), float(q["y"][i]), float(q["r"][i]), int(q["min_level"][i]), int(q["max_level"][i]),
+                            float(q["proj_xr"][i]), float(q["er_max"][i]), qd[i], blocked if use_blocked else None)
+            got = [res[f][i] for f in ("best_dist", "best_idx", "best_level", "best_dist2", "best_level2", "n_candidates", "best_idx2")]
+            assert got == ref.tolist(), (i, got, ref.tolist())
+    # the case is not vacuous: most queries find something even with 20 % of the keypoints blocked and the stereo
+    # gate on half of them, and a good share of the windows hold several candidates
+    assert (res["best_idx"] >= 0).mean() > 0.5 and (res["n_candidates"] > 3).mean() > 0.15

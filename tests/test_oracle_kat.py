@@ -617,3 +617,85 @@ def test_distinctive_descriptor_hand_cases():
         D = pop[d[:, None, :] ^ d[None, :, :]].sum(axis=2)
         med = np.sort(D, axis=1)[:, int(0.5 * (len(d) - 1))]
         assert got[p] == int(np.argmin(med))
+
+
+def test_frame_grid_features_in_area_vs_bruteforce():
+    """Frame::GetFeaturesInArea (src/Frame.cc:327-380): the same SET as a brute-force window test, in grid order
+    (cell column, cell row, keypoint index); level filter semantics (:349, 362-370)."""
+    rng = np.random.default_rng(5)
+    n = 1500
+    kx = rng.uniform(0, 1241, n).astype(np.float32)
+    ky = rng.uniform(0, 376, n).astype(np.float32)
+    koct = rng.integers(0, 8, n).astype(np.int32)
+    kx[:3], ky[:3] = [-5.0, 1300.0, 10.0], [10.0, 10.0, -3.0]        # outside the grid: never returned (PosInGrid :388)
+    w_inv, h_inv = np.float32(64) / np.float32(1241), np.float32(48) / np.float32(376)
+    g = O.OracleGrid(kx, ky, koct, np.zeros((n, 32), np.uint8), None, 0.0, 0.0, float(w_inv), float(h_inv))
+    for x, y, r, lo, hi in [(600, 200, 40, -1, -1), (5, 5, 30, 0, 3), (1235, 370, 25, 2, -1), (300, 100, 15.5, 3, 3),
+                            (-100, 50, 20, -1, -1), (700, 188, 400, 0, 7)]:
+        got = g.features_in_area(x, y, r, lo, hi)
+        posx = np.round((kx - 0) * w_inv).astype(int)              # round(): never .5 exactly for these random values
+        posy = np.round((ky - 0) * h_inv).astype(int)
+        ok = (posx >= 0) & (posx < 64) & (posy >= 0) & (posy < 48)
+        ok &= (np.abs(kx - np.float32(x)) < r) & (np.abs(ky - np.float32(y)) < r)
+        if lo > 0 or hi >= 0:
+            ok &= koct >= lo
+            if hi >= 0:
+                ok &= koct <= hi
+        # cells reached: floor/ceil of the window (:332-346)
+        cx0, cx1 = max(0, int(np.floor((x - r) * w_inv))), min(63, int(np.ceil((x + r) * w_inv)))
+        cy0, cy1 = max(0, int(np.floor((y - r) * h_inv))), min(47, int(np.ceil((y + r) * h_inv)))
+        ok &= (posx >= cx0) & (posx <= cx1) & (posy >= cy0) & (posy <= cy1)
+        want = sorted(np.nonzero(ok)[0], key=lambda i: (posx[i], posy[i], i))
+        assert got.tolist() == [int(i) for i in want]
+
+
+def test_search_area_best_second_rule():
+    """src/ORBmatcher.cc:71-115: strict '<' updates in list order, blocked keypoints and the right-coordinate gate."""
+    kx = np.array([100, 101, 102, 103, 104], np.float32)
+    ky = np.full(5, 50, np.float32)
+    koct = np.array([2, 2, 3, 2, 2], np.int32)
+    d = np.zeros((5, 32), np.uint8)
+    d[0, 0] = 0b00000111      # distance 3 to the zero query
+    d[1, 0] = 0b00000001      # 1
+    d[2, 0] = 0b00000001      # 1 (tie with index 1: the first stays best, this one becomes second)
+    d[3, 0] = 0b00111111      # 6
+    d[4, 0] = 0               # 0, but blocked / gated below
+    ur = np.array([-1, 90, 90, 90, 40], np.float32)
+    g = O.OracleGrid(kx, ky, koct, d, ur, 0.0, 0.0, 64 / 1241, 48 / 376)
+    q = np.zeros(32, np.uint8)
+    assert g.search(102, 50, 10, 1, 3, 0.0, -1.0, q).tolist() == [0, 4, 2, 1, 2, 5, 1]
+    blocked = np.array([0, 0, 0, 0, 1], np.uint8)
+    assert g.search(102, 50, 10, 1, 3, 0.0, -1.0, q, blocked).tolist() == [1, 1, 2, 1, 3, 5, 2]
+    # gate: |proj_xr - uRight| > er_max drops index 4 (uRight 40) but keeps the others (uRight 90) and index 0 (uRight <= 0)
+    assert g.search(102, 50, 10, 1, 3, 92.0, 5.0, q).tolist() == [1, 1, 2, 1, 3, 5, 2]
+    assert g.search(102, 50, 10, 3, 3, 0.0, -1.0, q).tolist() == [1, 2, 3, 256, -1, 1, -1]
+    assert g.search(500, 300, 10, -1, -1, 0.0, -1.0, q).tolist() == [256, -1, -1, 256, -1, 0, -1]
+
+
+def test_search_area_result_depends_only_on_its_two_holders():
+    """The replay rule of INTEGRATION.md: blocking a keypoint that holds neither the best nor the second place of a query
+    leaves that query's result unchanged, so a result is stale only if best_idx or best_idx2 got associated later."""
+    rng = np.random.default_rng(31)
+    n = 400
+    kx = rng.uniform(0, 300, n).astype(np.float32)
+    ky = rng.uniform(0, 200, n).astype(np.float32)
+    koct = rng.integers(0, 4, n).astype(np.int32)
+    d = rng.integers(0, 4, (n, 32)).astype(np.uint8)          # few distinct distances: many ties
+    g = O.OracleGrid(kx, ky, koct, d, None, 0.0, 0.0, 64 / 300, 48 / 200)
+    changed_by_holder = 0
+    for t in range(200):
+        x, y, r = float(rng.uniform(0, 300)), float(rng.uniform(0, 200)), float(rng.uniform(10, 40))
+        q = rng.integers(0, 4, 32).astype(np.uint8)
+        base = g.search(x, y, r, -1, -1, 0.0, -1.0, q)
+        cand = g.features_in_area(x, y, r, -1, -1)
+        if len(cand) < 3:
+            continue
+        for idx in rng.choice(cand, min(6, len(cand)), replace=False):
+            blocked = np.zeros(n, np.uint8)
+            blocked[idx] = 1
+            after = g.search(x, y, r, -1, -1, 0.0, -1.0, q, blocked)
+            if idx not in (base[1], base[6]):
+                assert after.tolist() == base.tolist()
+            else:
+                changed_by_holder += after.tolist() != base.tolist()
+    assert changed_by_holder > 20
