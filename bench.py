@@ -155,6 +155,34 @@ def other_configs(local_rank, dev):
     out["bow_transform_k10_L6"] = {"descriptors_per_s_batched": round(nbig / big, 1), "batch_descriptors": nbig,
                                    "latency_ms_2000_descriptors": round(float(np.median(lat)) * 1e3, 4),
                                    "hamming_distances_per_descriptor": 60}
+    # Frame grid + windowed search (N4): the SearchByProjection(Frame&, vpMapPoints, th) candidate loop for 1500 projected
+    # map points against the left frame's keypoints; host queries in, host results out (synchronous C call)
+    nl = int(n[0])
+    khost = kps[0, :nl].cpu().numpy()
+    dhost = desc[0, :nl].cpu().numpy()
+    kx, ky = np.ascontiguousarray(khost[:, 0]), np.ascontiguousarray(khost[:, 1])
+    koct = np.ascontiguousarray(khost[:, 5].view(np.int32))
+    urh = ur[:nl].cpu().numpy()
+    grid = capi.FrameGrid(kx, ky, koct, dhost, urh, 0.0, 0.0, float(np.float32(64) / np.float32(W)),
+                          float(np.float32(48) / np.float32(H)), device=local_rank)
+    rng = np.random.default_rng(7)
+    nq = 1500
+    src = rng.integers(0, nl, nq)
+    q = np.zeros(nq, capi.AREA_QUERY_DTYPE)
+    q["x"], q["y"] = kx[src] + rng.uniform(-3, 3, nq), ky[src] + rng.uniform(-3, 3, nq)
+    q["r"] = (4.0 * 1.2 ** koct[src]).astype(np.float32)
+    q["min_level"], q["max_level"] = koct[src] - 1, koct[src]
+    q["proj_xr"], q["er_max"] = q["x"] - 20, q["r"]
+    qd = np.ascontiguousarray(dhost[src])
+    res = grid.search(m, q, qd, None)
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        res = grid.search(m, q, qd, None)
+        lat.append(time.perf_counter() - t0)
+    out["search_by_projection_1500_windows"] = {"latency_ms_host_queries_to_host_results": round(float(np.median(lat)) * 1e3, 4),
+                                                "frame_keypoints": nl, "candidates_per_window": round(float(res["n_candidates"].mean()), 2),
+                                                "windows_with_match": int((res["best_idx"] >= 0).sum())}
     return out
 
 

@@ -499,8 +499,8 @@ struct AreaArgs {
     AreaResult *res;
 };
 
-__global__ __launch_bounds__(256) void search_area_kernel(AreaArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void search_area_kernel(AreaArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a.nq) return;
     const AreaQuery q = a.q[i];
     AreaResult out;
