@@ -1,0 +1,151 @@
+"""Golden fixtures of the ORB front end.
+
+The reference has no tests and cannot be built here (OpenCV is absent), so the fixtures under tests/golden/ are outputs
+of the CPU oracle on seeded synthetic inputs, written by tests/golden/make_golden.py in the build container and
+committed ("parity unpinned": they pin the oracle and the HIP path to each other and to history, not to a run of the
+reference).  This module defines the cases and how raw outputs are reduced to digests; the two providers (oracle, HIP
+through the C-ABI) live in make_golden.py / test_golden.py.  Nothing here imports the oracle or the library."""
+import hashlib
+import json
+import zlib
+from pathlib import Path
+
+import numpy as np
+
+from orb_slam2_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "front_end.json"
+
+EXTRACT_CASES = {            # BASELINE.json configs: KITTI stereo, TUM mono / RGB-D, EuRoC
+    "kitti_1241x376_2000": dict(w=1241, h=376, nfeatures=2000, seed=11),
+    "tum_640x480_1000": dict(w=640, h=480, nfeatures=1000, seed=12),
+    "euroc_752x480_1200": dict(w=752, h=480, nfeatures=1200, seed=13),
+    "small_233x229_300": dict(w=233, h=229, nfeatures=300, seed=14),   # level 7 is 65x64: one FAST cell
+}
+STEREO = dict(w=1241, h=376, nfeatures=2000, seed=15, bf=386.1448, b=0.5371657)   # KITTI00-02.yaml
+KNN = dict(nq=300, nr=5000, seed=16)
+BOW = dict(k=10, L=4, seed=17, n=3000, levelsup=2)
+DISTINCTIVE = dict(seed=18, points=400)
+AREA = dict(seed=19, nq=800)
+
+
+def crc(a) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def extract_inputs(name):
+    c = EXTRACT_CASES[name]
+    return synth.textured_image(c["w"], c["h"], synth.BASE_SEED + c["seed"]), c
+
+
+def extract_digest(img, levels, blurred, candidates, selected, kps, desc):
+    """levels / blurred: 8 u8 planes (blurred[l] may be None for a level without keypoints); candidates: 8 float32 [n,3]
+    (x, y, response in the reference's order); selected: 8 arrays of kept keypoints; kps: 28-byte records; desc [n,32]."""
+    per_level = []
+    for l in range(len(levels)):
+        per_level.append({
+            "size": [int(levels[l].shape[1]), int(levels[l].shape[0])],
+            "pyramid_crc32": crc(levels[l]),
+            "blurred_crc32": None if blurred[l] is None else crc(blurred[l]),
+            "fast_candidates": int(len(candidates[l])),
+            "fast_candidates_crc32": crc(np.asarray(candidates[l], np.float32)),
+            "kept": int(len(selected[l])),
+        })
+    raw = np.ascontiguousarray(kps).view(np.uint8).reshape(-1, 28)
+    return {"image_crc32": crc(img), "levels": per_level, "keypoints": int(len(raw)),
+            "first_32_keypoints_hex": [bytes(r).hex() for r in raw[:32]],
+            "keypoints_sha256": sha(raw), "descriptors_sha256": sha(desc)}
+
+
+def stereo_inputs():
+    return synth.stereo_pair(STEREO["w"], STEREO["h"], synth.BASE_SEED + STEREO["seed"])
+
+
+def stereo_digest(kl, kr, uright, depth):
+    return {"left_keypoints": int(len(kl)), "right_keypoints": int(len(kr)), "with_depth": int((depth > 0).sum()),
+            "mvuRight_sha256": sha(np.asarray(uright, np.float32)), "mvDepth_sha256": sha(np.asarray(depth, np.float32)),
+            "first_matches": [[int(i), float(uright[i]), float(depth[i])] for i in np.nonzero(depth > 0)[0][:8]]}
+
+
+def knn_inputs():
+    db = synth.random_descriptors(KNN["nr"], 1000 + KNN["seed"])
+    q = synth.planted_queries(db, KNN["nq"], 2000 + KNN["seed"], planted_frac=0.3)
+    db[KNN["nr"] // 2] = db[3]
+    q[0] = db[3]
+    return q, db
+
+
+def knn_digest(bd, bi, sd):
+    out = np.stack([np.asarray(bd, np.int32), np.asarray(bi, np.int32), np.asarray(sd, np.int32)])
+    return {"sha256": sha(out), "first_8": out[:, :8].T.tolist()}
+
+
+def bow_inputs():
+    co, ci, nd, wi, w = synth.random_vocabulary(BOW["k"], BOW["L"], 3000 + BOW["seed"])
+    f = synth.random_descriptors(BOW["n"], 4000 + BOW["seed"])
+    f[:200] = nd[(np.arange(200) * 11) % len(nd)]
+    return (co, ci, nd, wi, w), f
+
+
+def bow_digest(leaf, nid):
+    out = np.stack([np.asarray(leaf, np.int32), np.asarray(nid, np.int32)])
+    return {"sha256": sha(out), "first_8": out[:, :8].T.tolist()}
+
+
+def distinctive_inputs():
+    rng = np.random.default_rng(DISTINCTIVE["seed"])
+    sizes = np.concatenate([rng.integers(0, 30, DISTINCTIVE["points"]), [64, 65, 100, 1, 0, 2]])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = synth.random_descriptors(int(off[-1]), 5000 + DISTINCTIVE["seed"])
+    for p in range(0, len(sizes), 2):
+        if sizes[p] > 1:
+            base = desc[off[p]].copy()
+            for i in range(off[p], off[p + 1]):
+                d = base.copy()
+                for b in rng.integers(0, 256, int(rng.integers(0, 25))):
+                    d[b >> 3] ^= np.uint8(1 << (b & 7))
+                desc[i] = d
+    return desc, off
+
+
+def distinctive_digest(best):
+    best = np.asarray(best, np.int32)
+    return {"sha256": sha(best), "first_16": best[:16].tolist()}
+
+
+def area_inputs(kps, desc):
+    """Windows around the keypoints of the KITTI extraction case (taken from the provider's own extraction)."""
+    c = EXTRACT_CASES["kitti_1241x376_2000"]
+    rng = np.random.default_rng(AREA["seed"])
+    n, nq = len(kps), AREA["nq"]
+    kx, ky, koct = kps["x"].copy(), kps["y"].copy(), kps["octave"].astype(np.int32)
+    ur = np.where(rng.uniform(size=n) < 0.5, kx - rng.uniform(1, 60, n), -1).astype(np.float32)
+    src = rng.integers(0, n, nq)
+    q = {"x": (kx[src] + rng.uniform(-5, 5, nq)).astype(np.float32), "y": (ky[src] + rng.uniform(-5, 5, nq)).astype(np.float32)}
+    q["r"] = (rng.choice([2.5, 4.0, 12.0], nq) * (1.2 ** koct[src])).astype(np.float32)
+    q["min_level"], q["max_level"] = (koct[src] - 1).astype(np.int32), koct[src].astype(np.int32)
+    q["proj_xr"] = (q["x"] - rng.uniform(1, 60, nq)).astype(np.float32)
+    q["er_max"] = np.where(rng.uniform(size=nq) < 0.5, q["r"], -1).astype(np.float32)
+    qd = desc[src].copy()
+    for i in range(nq):
+        for b in rng.integers(0, 256, 12):
+            qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    blocked = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    grid = dict(kx=kx, ky=ky, koct=koct, ur=ur, min_x=0.0, min_y=0.0,
+                w_inv=float(np.float32(64) / np.float32(c["w"])), h_inv=float(np.float32(48) / np.float32(c["h"])))
+    return grid, q, qd, blocked
+
+
+def area_digest(rows):
+    """rows: int32 [nq, 7] = best_dist, best_idx, best_level, best_dist2, best_level2, n_candidates, best_idx2"""
+    rows = np.asarray(rows, np.int32)
+    return {"sha256": sha(rows), "first_8": rows[:8].tolist(), "with_match": int((rows[:, 1] >= 0).sum())}
+
+
+def load():
+    with open(GOLDEN) as fh:
+        return json.load(fh)
