@@ -49,6 +49,10 @@ struct FastTile {
 static_assert(sizeof(FastTile) == 56, "FastTile");
 
 constexpr int kFastListCap = 1024;    // survivor records (one per lane and row) a wave can hold for its strip (dense texture: ~150)
+// The most a strip can produce: every lane of every row (one kept pixel per 2x2 block still allows a record per dword and
+// row) plus one split record per inner cell edge: (64 + 7) x 60 rows.  The host switches a handle to the kernel variant
+// with this capacity (one wave per workgroup, 34 KB LDS) when a wave of the normal variant reports an overflow.
+constexpr int kFastListCapMax = 4288;
 
 struct FastArgs {
     Geom g;
@@ -127,12 +131,13 @@ __device__ __forceinline__ void fast_row_pairs(uint32_t raw, uint32_t (&q)[8]) {
     q[7] = ER;
 }
 
-__global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
-    __shared__ uint2 sList[4][kFastListCap];
-    __shared__ int sCellMax[4][kFastMaxCells];
-    __shared__ int4 sSeg[4][kFastMaxSeg];   // per segment: first lane, first cell (in wave), x and y of its origin in the output
+template <int CAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
+    __shared__ uint2 sList[WAVES][CAP];
+    __shared__ int sCellMax[WAVES][kFastMaxCells];
+    __shared__ int4 sSeg[WAVES][kFastMaxSeg];   // per segment: first lane, first cell (in wave), x and y of its origin in the output
     const int lane = threadIdx.x & 63;
-    const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ti = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (ti >= a.nTiles) return;
     const FastTile &t = a.tiles[ti];
     const int f = blockIdx.y;
@@ -236,14 +241,14 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
             if (Bs != 0) {   // wave-uniform, rare
                 pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(Bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bs, 0));
                 if (PdA != 0 && PdB != 0) {
-                    if (pos < kFastListCap) sList[wvi][pos] = make_uint2(PdA, recTag | ((uint32_t)o << 18));
-                    if (pos + 1 < kFastListCap) sList[wvi][pos + 1] = make_uint2(PdB, recTag | ((uint32_t)o << 18));
-                } else if (Pd != 0 && pos < kFastListCap) {
+                    if (pos < CAP) sList[wvi][pos] = make_uint2(PdA, recTag | ((uint32_t)o << 18));
+                    if (pos + 1 < CAP) sList[wvi][pos + 1] = make_uint2(PdB, recTag | ((uint32_t)o << 18));
+                } else if (Pd != 0 && pos < CAP) {
                     sList[wvi][pos] = make_uint2(Pd, recTag | ((uint32_t)o << 18));
                 }
                 listCount += __popcll(Bm) + __popcll(Bs);
             } else {
-                if (Pd != 0 && pos < kFastListCap) sList[wvi][pos] = make_uint2(Pd, recTag | ((uint32_t)o << 18));
+                if (Pd != 0 && pos < CAP) sList[wvi][pos] = make_uint2(Pd, recTag | ((uint32_t)o << 18));
                 listCount += __popcll(Bm);
             }
         }
@@ -311,9 +316,9 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(FastArgs a) {
     // ---- flush: per-cell maximum -> threshold, one reservation in the level's dense array, candidates grouped by cell
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (listCount > kFastListCap) {
+    if (listCount > CAP) {
         if (lane == 0) atomicOr(a.status, 4);
-        listCount = kFastListCap;
+        listCount = CAP;
     }
     // a record's lane gives its segment (sSeg), the segment gives the cell numbering and the output origin
     auto rec_seg = [&](uint32_t recLane) {

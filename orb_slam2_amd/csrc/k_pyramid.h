@@ -119,4 +119,28 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
     }
 }
 
+// Any other ratio (scale factors of 2 whose rounded level sizes push the ratio past the 12-byte window, factors >= 3,
+// up-sampling): one lane per 4 output pixels of one row, byte gathers.  Same arithmetic, no window assumption.
+__global__ __launch_bounds__(256) void pyr_resize_generic_kernel(ResizeArgs a) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int dy = blockIdx.y, f = blockIdx.z;
+    if (x0 >= a.dw) return;
+    const RszTab yt = a.ytab[dy];
+    const int r0 = min(max(yt.ofs, 0), a.sh - 1), r1 = min(max(yt.ofs + 1, 0), a.sh - 1);
+    const uint32_t b0 = (uint32_t)yt.coef & 0xffffu, b1 = (uint32_t)yt.coef >> 16;
+    const uint8_t *p0 = a.src + (size_t)f * a.sFrameStride + (size_t)r0 * a.sPitch;
+    const uint8_t *p1 = a.src + (size_t)f * a.sFrameStride + (size_t)r1 * a.sPitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const RszTab xt = a.xtab[x0 + i];                    // padded past dw with the last entry
+        const int s0 = xt.ofs, s1 = min(xt.ofs + 1, a.sw - 1);
+        const uint32_t a0 = (uint32_t)xt.coef & 0xffffu, a1 = (uint32_t)xt.coef >> 16;
+        const uint32_t H0 = (p0[s0] * a0 + p0[s1] * a1) >> 4, H1 = (p1[s0] * a0 + p1[s1] * a1) >> 4;
+        const uint32_t d = (((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2u) >> 2;
+        out |= (d & 0xffu) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t *>(a.dst + (size_t)f * a.dFrameStride + (size_t)dy * a.dPitch + x0) = out;
+}
+
 }  // namespace orbfe

@@ -110,7 +110,7 @@ struct orbfe_extractor {
     bool haveGeom = false;
     std::vector<RszTab> hRsz;           // all levels' x and y tables
     std::vector<int> rszRows;           // output rows per wavefront of the resize kernel, per level
-    std::vector<char> rszWide;          // level needs the 12-byte source window (scale factor ~2 and above)
+    std::vector<char> rszWide;          // 0: 8-byte source window, 1: 12-byte window (scale factor ~2), 2: gather kernel
     std::vector<BlurTile> hBlurTiles;
     std::vector<FastTile> hFastTiles;
     DevBuf dRsz, dBlurTiles, dFastTiles, dDescMask;
@@ -129,6 +129,10 @@ struct orbfe_extractor {
     ImgSrc last{};
     int lastFrames = 0;
     bool overflow = false;
+    bool fastBigList = false;           // FAST runs with the large per-wave survivor list (set after an overflow report)
+    struct BatchCall { const uint8_t *imgs; int F, w, h, stride; size_t frameStride; orbfe_keypoint *kps; uint8_t *desc;
+                       int32_t *counts; int cap; } lastCall{};
+    int batchesInFlight = 0;            // orbfe_extract_batch calls since the last synchronisation
     int quadtreeMode = ORBFE_QUADTREE_DEVICE;   // orbfe_set_quadtree_mode
     bool lastOnHost = false;                    // did the last call bring candidates / kept keypoints to the host
     PinBuf hStatus;
@@ -150,6 +154,12 @@ struct orbfe_extractor {
     long stageFrames = 0;
     long candTotal = 0, kpTotal = 0;
 };
+
+constexpr int kRerunBigList = 1;   // internal: eval_status asks for the batch to be run again (large FAST survivor list)
+static const char *const kBigListMsg =
+    "a FAST strip produced more survivor records than the normal kernel variant holds and more than one asynchronous batch "
+    "was in flight: the handle now uses the large-list variant, run those batches again";
+static int fetch_status(orbfe_extractor *e);
 
 namespace {
 
@@ -302,8 +312,20 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
         }
         L.cellBase = cellBase;
         cellBase += L.nCols * L.nRows;
-        const int detArea = std::max(1, (L.w - 2 * kEdge) * (L.h - 2 * kEdge));
-        L.candCap = std::min(60000, std::max(1024, detArea / 12));
+        {
+            // candidate capacity = the most the level can yield: strict 3x3 NMS keeps at most one pixel of any 2x2 block, and
+            // the cells' scan ranges tile the detection area (the reference's vector just grows; this one cannot overflow)
+            int sx = 0, sy = 0;
+            for (int j = 0; j < L.nCols; j++) {
+                const int xs = kEdge + j * L.wCell, xe = std::min(xs + L.wCell, L.w - kEdge);
+                if (xe > xs) sx += (xe - xs + 1) / 2;
+            }
+            for (int i = 0; i < L.nRows; i++) {
+                const int ys = kEdge + i * L.hCell, ye = std::min(ys + L.hCell, L.h - kEdge);
+                if (ye > ys) sy += (ye - ys + 1) / 2;
+            }
+            L.candCap = std::max(64, sx * sy);
+        }
         L.candOff = candOff;
         candOff += L.candCap;
         // quadtree roots (:543-545)
@@ -347,9 +369,8 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
                 // (pixel 3 past the last column is a padded table entry whose result lands in the row padding)
                 if (end2 - b12 > 7 || end3 - b12 > 10 || (x0 + 3 < L.w && xt[l3].ofs - b12 < 3)) wide = false;
             }
-            if (!narrow && !wide)
-                return fail(ORBFE_ERR_UNSUPPORTED, "scale factor outside the resize kernel's window (1 < scale < 3)");
-            e->rszWide[l] = !narrow;
+            e->rszWide[l] = narrow ? 0 : wide ? 1 : 2;   // 2: the gather kernel, any ratio
+            if (L.h > 65535) return fail(ORBFE_ERR_UNSUPPORTED, "image larger than 65535 pixels on a side");
             e->rszRows[l] = rows;
         }
         for (int ty = 0; ty * kBlurRows < L.h; ty++)
@@ -386,19 +407,29 @@ int ensure_workspace(orbfe_extractor *e, int F) {
     {
         const size_t lcBytes = (size_t)F * kMaxLevels * sizeof(int), ctBytes = (size_t)F * g.totalCells * sizeof(int2);
         e->countersBytes = 64 + lcBytes + ctBytes;
+        if (e->countersBytes > e->dCounters.bytes) {   // about to move: whatever an unfinished batch reported goes first
+            if (int rc = fetch_status(e)) return rc == kRerunBigList ? fail(ORBFE_ERR_CAPACITY, kBigListMsg) : rc;
+        }
         HIPCHK(e->dCounters.ensure(e->countersBytes));
+        if (e->pStatus != (int *)e->dCounters.p) HIPCHK(hipMemsetAsync(e->dCounters.p, 0, 64, e->stream));
         e->pStatus = (int *)e->dCounters.p;
         e->pLevelCount = (int *)((uint8_t *)e->dCounters.p + 64);
         e->pCellTab = (int2 *)((uint8_t *)e->dCounters.p + 64 + lcBytes);
     }
     HIPCHK(e->dSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
     HIPCHK(e->dSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
+    HIPCHK(e->hStatus.ensure(16));
+    return ORBFE_OK;
+}
+
+// pinned host mirrors of the candidate / selection arrays: only the host quadtree and the debug exports read them
+int ensure_host_mirrors(orbfe_extractor *e, int F) {
+    const Geom &g = e->g;
     HIPCHK(e->hCand.ensure((size_t)F * g.candFrameCap * sizeof(Cand)));
     HIPCHK(e->hLevelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
     HIPCHK(e->hCellTab.ensure((size_t)F * g.totalCells * sizeof(int2)));
     HIPCHK(e->hSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
     HIPCHK(e->hSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
-    HIPCHK(e->hStatus.ensure(16));
     return ORBFE_OK;
 }
 
@@ -430,6 +461,7 @@ bool quadtree_on_host(const orbfe_extractor *e) {
 int host_quadtree_stage(orbfe_extractor *e, int F) {
     const Geom &g = e->g;
     hipStream_t st = e->stream;
+    if (int rc = ensure_host_mirrors(e, F)) return rc;
     HIPCHK(hipMemcpyAsync(e->hLevelCount.p, e->pLevelCount, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(e->hCellTab.p, e->pCellTab, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(e->hCand.p, e->dCand.p, (size_t)F * g.candFrameCap * sizeof(Cand), hipMemcpyDeviceToHost, st));
@@ -582,13 +614,16 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.nStrips = (L.w + kRszStripPx - 1) / kRszStripPx;
         a.rows = e->rszRows[l];
         a.nRowBlocks = (L.h + a.rows - 1) / a.rows;
-        if (e->rszWide[l])
+        if (e->rszWide[l] == 2)
+            hipLaunchKernelGGL(pyr_resize_generic_kernel, dim3((L.w + 1023) / 1024, L.h, F), dim3(256), 0, st, a);
+        else if (e->rszWide[l])
             hipLaunchKernelGGL(pyr_resize_kernel<true>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL(pyr_resize_kernel<false>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
     }
     // K3: FAST over every cell of every level
-    HIPCHK(hipMemsetAsync(e->dCounters.p, 0, e->countersBytes, st));
+    // (the status word in the first 64 bytes stays: it collects over batches until the host has read it)
+    HIPCHK(hipMemsetAsync((uint8_t *)e->dCounters.p + 64, 0, e->countersBytes - 64, st));
     if (profAny) HIPCHK(hipEventRecord(e->ev[1], st));
     {
         const int iniTh = std::min(std::max(e->p.ini_th_fast, 0), 255), minTh = std::min(std::max(e->p.min_th_fast, 0), 255);
@@ -604,7 +639,10 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.iniTh = std::max(iniTh, minTh);
         a.minTh = std::min(iniTh, minTh);
         if (iniTh < minTh) a.iniTh = a.minTh = iniTh;
-        hipLaunchKernelGGL(fast_cells_kernel, dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
+        if (e->fastBigList)   // a strip of an earlier batch produced more survivor records than the normal variant holds
+            hipLaunchKernelGGL((fast_cells_kernel<kFastListCapMax, 1>), dim3(a.nTiles, F), dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL((fast_cells_kernel<kFastListCap, 4>), dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
     }
     if (profAny) HIPCHK(hipEventRecord(e->ev[2], st));
     const bool hostTree = quadtree_on_host(e);
@@ -693,8 +731,8 @@ int orbfe_device_count(void) {
 int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extractor **out) {
     if (!params || !out) return fail(ORBFE_ERR_ARG, "null argument");
     if (params->nlevels < 1 || params->nlevels > kMaxLevels) return fail(ORBFE_ERR_ARG, "nlevels must be in [1,16]");
-    if (!(params->scale_factor > 1.0f) || params->scale_factor > 2.0f)
-        return fail(ORBFE_ERR_UNSUPPORTED, "scale_factor must be in (1, 2]");
+    if (!(params->scale_factor > 1.0f) || !(params->scale_factor <= 16.0f))   // 1 makes the reference's quota formula 0/0
+        return fail(ORBFE_ERR_UNSUPPORTED, "scale_factor must be in (1, 16]");
     if (params->nfeatures < 1) return fail(ORBFE_ERR_ARG, "nfeatures must be positive");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -812,12 +850,20 @@ int orbfe_debug_qt_times(unsigned long long *out, int n) {
 
 void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream : nullptr; }
 
-// after the stream has drained: fold the device status word (device quadtree) into the handle
+// after the stream has drained: fold the device status word into the handle.  The word is sticky on the device (batches
+// enqueued back to back all report into it) and cleared here.  kRerunBigList: a FAST strip overflowed the normal survivor
+// list; the handle has been switched to the large-list kernel and the caller runs the batch again.
 static int eval_status(orbfe_extractor *e) {
     const int st = *(const int *)e->hStatus.p;
+    if (st) (void)hipMemsetAsync(e->pStatus, 0, sizeof(int), e->stream);
+    *(int *)e->hStatus.p = 0;
     if (st & 1) e->overflow = true;
     if (st & 2) return fail(ORBFE_ERR_CAPACITY, "quadtree node table overflow");
-    if (st & 4) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list of a strip overflowed (more than 1024 lane records in 8 cells)");
+    if (st & 4) {
+        if (e->fastBigList) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list overflowed its upper bound (internal error)");
+        e->fastBigList = true;
+        return kRerunBigList;
+    }
     if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
     return ORBFE_OK;
 }
@@ -833,7 +879,20 @@ int orbfe_synchronize(orbfe_extractor *e) {
     if (!e) return fail(ORBFE_ERR_ARG, "null extractor");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    return fetch_status(e);
+    int rc = fetch_status(e);
+    const int pending = e->batchesInFlight;
+    e->batchesInFlight = 0;
+    if (rc == kRerunBigList) {
+        // an asynchronous batch: its arguments are still the caller's to keep alive until this call, so it can be run again
+        if (pending != 1) return fail(ORBFE_ERR_CAPACITY, kBigListMsg);
+        const orbfe_extractor::BatchCall c = e->lastCall;
+        rc = run_batch(e, c.imgs, c.F, c.w, c.h, c.stride, c.frameStride, c.kps, c.desc, c.counts, c.cap);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(e->stream));
+        rc = fetch_status(e);
+        e->batchesInFlight = 0;
+    }
+    return rc;
 }
 
 int orbfe_set_quadtree_mode(orbfe_extractor *e, int mode) {
@@ -854,11 +913,9 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
     HIPCHK(hipSetDevice(e->device));
     int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap);
     if (rc) return rc;
-    if (sync) {
-        HIPCHK(hipStreamSynchronize(e->stream));
-        return fetch_status(e);
-    }
-    return ORBFE_OK;
+    e->lastCall = {dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap};
+    e->batchesInFlight++;
+    return sync ? orbfe_synchronize(e) : ORBFE_OK;
 }
 
 int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stride, orbfe_keypoint *kps, int cap,
@@ -885,18 +942,22 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
     HIPCHK(e->hImg.ensure(fs));
     for (int y = 0; y < h; y++) memcpy((uint8_t *)e->hImg.p + (size_t)y * pitch, img + (size_t)y * stride, (size_t)w);
     HIPCHK(hipMemcpyAsync(e->dImg.p, e->hImg.p, fs, hipMemcpyHostToDevice, e->stream));
-    rc = run_batch(e, (const uint8_t *)e->dImg.p, 1, w, h, pitch, round_up((int)fs, 16), (orbfe_keypoint *)e->dKps.p,
-                   (uint8_t *)e->dDesc.p, (int32_t *)e->dCounts.p, icap);
-    if (rc) return rc;
-    // count, keypoints and descriptors come back together (at most selFrameCap entries, ~130 KB): one synchronisation
-    HIPCHK(hipMemcpyAsync(e->hCounts.p, e->dCounts.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->hKps.p, e->dKps.p, (size_t)icap * sizeof(KeyPointOut), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->hDesc.p, e->dDesc.p, (size_t)icap * 32, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->hStatus.p, e->pStatus, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    const int n = *(int *)e->hCounts.p;
+    int n = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = run_batch(e, (const uint8_t *)e->dImg.p, 1, w, h, pitch, round_up((int)fs, 16), (orbfe_keypoint *)e->dKps.p,
+                       (uint8_t *)e->dDesc.p, (int32_t *)e->dCounts.p, icap);
+        if (rc) return rc;
+        // count, keypoints and descriptors come back together (at most selFrameCap entries, ~130 KB): one synchronisation
+        HIPCHK(hipMemcpyAsync(e->hCounts.p, e->dCounts.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->hKps.p, e->dKps.p, (size_t)icap * sizeof(KeyPointOut), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->hDesc.p, e->dDesc.p, (size_t)icap * 32, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->hStatus.p, e->pStatus, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        n = *(int *)e->hCounts.p;
+        rc = eval_status(e);
+        if (rc != kRerunBigList) break;   // otherwise once more with the large survivor list (the image is still in dImg)
+    }
     if (n_out) *n_out = n;
-    rc = eval_status(e);
     if (rc) return rc;
     if (n > cap) return fail(ORBFE_ERR_CAPACITY, "keypoint buffer too small");
     if (n == 0) return ORBFE_OK;
@@ -962,6 +1023,7 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
     if (what == 2) {
         // candidates in the reference's order: read the level's dense array + cell table back and walk the cells
         const int F = e->lastFrames;
+        if (int rc = ensure_host_mirrors(e, F)) return rc;
         HIPCHK(hipMemcpy(e->hLevelCount.p, e->pLevelCount, (size_t)F * kMaxLevels * sizeof(int), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(e->hCellTab.p, e->pCellTab, (size_t)F * g.totalCells * sizeof(int2), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy((Cand *)e->hCand.p + (size_t)frame * g.candFrameCap + L.candOff,

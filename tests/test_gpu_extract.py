@@ -1,6 +1,8 @@
 """GPU parity of the extractor: liborbfe (HIP, through the C-ABI) against the CPU oracle, stage by stage and end to end.
 Bar (BASELINE.json north_star): pyramid levels, FAST corners, kept keypoints, descriptors bit-exact; angles within
 1e-3 degrees (in practice identical floats)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -190,3 +192,89 @@ def test_fast_thresholds(ini_th, min_th):
     img = synth.textured_image(752, 480, synth.BASE_SEED + 500 + ini_th)
     img[:, :200] = (img[:, :200].astype(np.int32) // 8 + 100).astype(np.uint8)      # low-contrast band: cells that fall back
     _stage_check(img, 1000, 1.2, 8, ini_th, min_th)
+
+
+def _fuzz_image(rng, w, h, kind, seed):
+    img = synth.textured_image(w, h, synth.BASE_SEED + seed)
+    if kind == "low_contrast":            # most cells fall back to minTh, many find nothing at all
+        img = (img.astype(np.int32) // int(rng.integers(6, 20)) + int(rng.integers(0, 200))).astype(np.uint8)
+    elif kind == "flat_regions":          # constant blocks: empty cells, empty levels, plateaus of equal scores
+        for _ in range(int(rng.integers(2, 8))):
+            x0, y0 = int(rng.integers(0, w - 8)), int(rng.integers(0, h - 8))
+            x1, y1 = int(rng.integers(x0 + 8, w + 1)), int(rng.integers(y0 + 8, h + 1))
+            img[y0:y1, x0:x1] = int(rng.integers(0, 256))
+    elif kind == "saturated":             # values at 0 / 255: u8 wrap and saturation paths of blur and resize
+        img = np.where(img > 128, 255, 0).astype(np.uint8)
+    elif kind == "noise":                 # a corner nearly everywhere: candidate lists at their largest
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("ORBFE_FUZZ_CASES", "40"))))
+def test_fuzz_configurations(case):
+    """Seeded random configurations (size, quota, scale factor, level count, thresholds, image statistics), every stage
+    bit-exact against the oracle.  Configurations the reference itself cannot run (a level smaller than one FAST cell,
+    portrait detection area) are avoided by construction."""
+    rng = np.random.default_rng(9000 + case)
+    scale = float(rng.choice([1.1, 1.15, 1.2, 1.2, 1.25, 1.3, 1.41, 1.5, 1.7, 2.0]))
+    nlevels = int(rng.integers(1, 11))
+    w = int(rng.integers(224, 1500))
+    h = int(rng.integers(224, min(w, 1100) + 1))                    # landscape or square: nIni = round(W/H) >= 1
+    while nlevels > 1 and min(w, h) / scale ** (nlevels - 1) < 72:   # smallest level holds one 30-px cell plus borders
+        nlevels -= 1
+    nfeatures = int(rng.choice([30, 100, 500, 1000, 2000, 3500]))
+    ini_th = int(rng.integers(8, 45))
+    min_th = int(rng.integers(2, ini_th + 1))
+    kind = str(rng.choice(["textured", "textured", "low_contrast", "flat_regions", "saturated", "noise"]))
+    img = _fuzz_image(rng, w, h, kind, 700 + case)
+    cfg = (w, h, nfeatures, scale, nlevels, ini_th, min_th, kind)
+    try:
+        _stage_check(img, nfeatures, scale, nlevels, ini_th, min_th)
+    except AssertionError as e:
+        raise AssertionError(f"config {cfg}: {e}") from e
+
+
+def test_dense_noise_switches_to_the_large_survivor_list():
+    """Uniform noise at minTh = 2: a FAST strip yields more survivor records than the normal kernel variant keeps in LDS.
+    The handle reruns the batch with the large-list variant -- transparently on the synchronous paths and in
+    orbfe_synchronize() for a single asynchronous batch -- and the results stay bit-exact."""
+    torch = pytest.importorskip("torch")
+    w, h = 1491, 344
+    img = np.random.default_rng(9176).integers(0, 256, (h, w)).astype(np.uint8)
+    o = O.OracleExtractor(100, 2.0, 3, 35, 2)
+    ko, do = o.extract(img)
+    assert sum(len(o.candidates(l)) for l in range(3)) > 40000        # about one pixel in nine survives
+    g = capi.ORBextractor(100, 2.0, 3, 35, 2)
+    kg, dg = g(img)                                                   # host image path: retried inside the call
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    stride = (w + 63) // 64 * 64
+    host = np.zeros((3, h, stride), np.uint8)
+    host[:, :, :w] = img
+    host[1, :, :w] = synth.textured_image(w, h, synth.BASE_SEED + 3)  # an ordinary frame between two noise frames
+    k1, d1 = o.extract(np.ascontiguousarray(host[1, :, :w]))
+    frames = torch.from_numpy(host).cuda()
+    cap = 200
+    for sync in (True, False):
+        g2 = capi.ORBextractor(100, 2.0, 3, 35, 2)                    # a fresh handle: starts with the normal variant
+        kps = torch.zeros((3, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((3, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+        g2.extract_batch_device(frames.data_ptr(), 3, w, h, stride, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
+                                cap, sync=sync)
+        if not sync:
+            g2.synchronize()                                          # reruns the one batch in flight
+        n = cnt.cpu().numpy()
+        kh = kps.cpu().numpy().view(np.uint8).reshape(3, cap, 28)
+        dh = desc.cpu().numpy()
+        for f, (kr, dr) in enumerate([(ko, do), (k1, d1), (ko, do)]):
+            assert n[f] == len(kr)
+            assert np.array_equal(kh[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), kr), (sync, f)
+            assert np.array_equal(dh[f, :n[f]], dr), (sync, f)
+
+
+@pytest.mark.parametrize("w,h,scale,nlevels", [(1434, 605, 2.0, 4), (1245, 574, 2.0, 3), (1400, 1000, 3.0, 3), (1300, 900, 2.5, 3)])
+def test_resize_ratios_outside_the_register_windows(w, h, scale, nlevels):
+    """Level sizes are rounded, so a scale factor of 2 can give a level ratio slightly above 2 (1434 -> 717 -> 358); those
+    and factors of 2.5 / 3 go through the gather variant of the resize kernel.  Every stage bit-exact."""
+    img = synth.textured_image(w, h, synth.BASE_SEED + w)
+    assert _stage_check(img, 800, scale, nlevels) > 100
