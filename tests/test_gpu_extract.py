@@ -278,3 +278,31 @@ def test_resize_ratios_outside_the_register_windows(w, h, scale, nlevels):
     and factors of 2.5 / 3 go through the gather variant of the resize kernel.  Every stage bit-exact."""
     img = synth.textured_image(w, h, synth.BASE_SEED + w)
     assert _stage_check(img, 800, scale, nlevels) > 100
+
+
+def test_two_extractors_from_two_host_threads():
+    """The reference runs the left and right extractor objects in two threads (src/Frame.cc:78-81).  Distinct handles are
+    independent (own stream, own workspace, thread-local error string): concurrent calls give the single-threaded results."""
+    import threading
+    left, right = synth.stereo_pair(1241, 376, synth.BASE_SEED + 404)
+    imgs = [left, right]
+    ex = [capi.ORBextractor(2000, 1.2, 8, 20, 7) for _ in range(2)]
+    ref = [O.OracleExtractor(2000, 1.2, 8, 20, 7).extract(im) for im in imgs]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(25):
+                k, d = ex[i](imgs[i])
+                if not (np.array_equal(k, ref[i][0]) and np.array_equal(d, ref[i][1])):
+                    errors.append((i, "mismatch"))
+                    return
+        except Exception as e:      # noqa: BLE001 - reported below
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
