@@ -183,6 +183,29 @@ def other_configs(local_rank, dev):
     out["search_by_projection_1500_windows"] = {"latency_ms_host_queries_to_host_results": round(float(np.median(lat)) * 1e3, 4),
                                                 "frame_keypoints": nl, "candidates_per_window": round(float(res["n_candidates"].mean()), 2),
                                                 "windows_with_match": int((res["best_idx"] >= 0).sum())}
+    # SearchByBoW loops (a-11): 1500 key-frame features against 2000 frame features spread over 100 shared vocabulary nodes
+    # (ORBvoc: 10-ary, 6 levels, FeatureVector at level 2), host arrays in, host matches out
+    n1, n2, nn = 1500, 2000, 100
+    d2 = synth.random_descriptors(n2, 123)
+    srcb = rng.integers(0, n2, n1)
+    d1 = d2[srcb].copy()
+    d1[:, :3] ^= rng.integers(0, 256, (n1, 3)).astype(np.uint8)
+    node2 = rng.integers(0, nn, n2)
+    node1 = node2[srcb]
+
+    def csr(node):
+        order = [np.nonzero(node == k)[0] for k in range(nn)]
+        return (np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32), np.concatenate(order).astype(np.int32))
+    (o1, i1), (o2, i2) = csr(node1), csr(node2)
+    mt = m.search_by_bow(d1, None, d2, None, o1, i1, o2, i2, 50, 0.7)
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        mt = m.search_by_bow(d1, None, d2, None, o1, i1, o2, i2, 50, 0.7)
+        lat.append(time.perf_counter() - t0)
+    out["search_by_bow_1500x2000_100_nodes"] = {"latency_ms_host_arrays_to_host_matches": round(float(np.median(lat)) * 1e3, 4),
+                                                "matches": int((mt >= 0).sum()),
+                                                "hamming_distances": int(sum((o1[k + 1] - o1[k]) * (o2[k + 1] - o2[k]) for k in range(nn)))}
     return out
 
 

@@ -7,12 +7,16 @@
 //   * Frame::ComputeStereoMatches as a whole (src/Frame.cc:466-640), SAD refinement and median gate included:
 //     orbfe::StereoMatcher below -- no host copy of mvImagePyramid is read
 //   * batched best/second-best for the BoW / projection searches: orbfe_match_knn2 / orbfe_match_csr in orbfe.h.
+//   * SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:159-288) and SearchByBoW(KeyFrame*, KeyFrame*, ...) (:522-655):
+//     orbfe::BowMatcher below
 //   * Frame::GetFeaturesInArea (src/Frame.cc:327-380) + the candidate loop of SearchByProjection(Frame&, vpMapPoints, th)
 //     (src/ORBmatcher.cc:45-129): orbfe::ProjectionSearch below
 // INTEGRATION.md shows the two-line patches.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
+#include <map>
 #include <vector>
 
 #include "orbfe.h"
@@ -211,6 +215,108 @@ private:
     orbfe_frame_grid *g_;
     int n_ = 0;
     long requeried_ = 0;
+};
+
+// ORBmatcher::SearchByBoW, both overloads.  Side 1 is the KeyFrame whose MapPoints are looked up (pKF / pKF1), side 2 the
+// Frame (or pKF2).  fv1 / fv2 are the DBoW2::FeatureVector maps (node id -> feature indices); valid1[i] != 0 where side 1
+// has a MapPoint that is not bad (:191-197, :558-562); blocked2 (may be empty) marks side-2 features that cannot be matched
+// (KeyFrame / KeyFrame: no MapPoint or a bad one, :574-580).  maxDist = TH_LOW for the Frame overload (<=, :228) and
+// TH_LOW - 1 for the KeyFrame overload (<, :598).  The merge walk (:180-264) and the rotation histogram with
+// ComputeThreeMaxima (:236-246, :267-285, :1601-1642) run here on the host; the distance loops run on the device, one
+// wavefront per shared node (orbfe_search_by_bow).  match12[i] = side-2 feature matched to side-1 feature i, or -1;
+// *nmatches is the reference's return value.
+class BowMatcher {
+public:
+    typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;   // DBoW2::FeatureVector
+    explicit BowMatcher(int device = 0) : m_(nullptr) { orbfe_matcher_create(device, &m_); }
+    ~BowMatcher() { orbfe_matcher_destroy(m_); }
+    int SearchByBoW(const FeatureVector &fv1, const cv::Mat &desc1, const std::vector<cv::KeyPoint> &keys1,
+                    const std::vector<unsigned char> &valid1, const FeatureVector &fv2, const cv::Mat &desc2,
+                    const std::vector<cv::KeyPoint> &keys2, const std::vector<unsigned char> &blocked2, int maxDist, float nnRatio,
+                    bool checkOrientation, std::vector<int> &match12, int *nmatches) {
+        const int n1 = (int)keys1.size(), n2 = (int)keys2.size();
+        match12.assign(n1, -1);
+        *nmatches = 0;
+        // the merge walk of :180-264: nodes present in both maps, in ascending node id
+        std::vector<int32_t> off1(1, 0), off2(1, 0), idx1, idx2;
+        FeatureVector::const_iterator it1 = fv1.begin(), it2 = fv2.begin();
+        while (it1 != fv1.end() && it2 != fv2.end()) {
+            if (it1->first == it2->first) {
+                idx1.insert(idx1.end(), it1->second.begin(), it1->second.end());
+                idx2.insert(idx2.end(), it2->second.begin(), it2->second.end());
+                off1.push_back((int32_t)idx1.size());
+                off2.push_back((int32_t)idx2.size());
+                ++it1;
+                ++it2;
+            } else if (it1->first < it2->first) {
+                it1 = fv1.lower_bound(it2->first);
+            } else {
+                it2 = fv2.lower_bound(it1->first);
+            }
+        }
+        if (off1.size() == 1 || n1 == 0 || n2 == 0) return ORBFE_OK;
+        std::vector<unsigned char> d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+        for (int i = 0; i < n1; i++) for (int b = 0; b < 32; b++) d1[(size_t)i * 32 + b] = desc1.ptr(i)[b];
+        for (int i = 0; i < n2; i++) for (int b = 0; b < 32; b++) d2[(size_t)i * 32 + b] = desc2.ptr(i)[b];
+        const int rc = orbfe_search_by_bow(m_, d1.data(), valid1.empty() ? nullptr : valid1.data(), n1, d2.data(),
+                                           blocked2.empty() ? nullptr : blocked2.data(), n2, off1.data(), idx1.data(), off2.data(),
+                                           idx2.data(), (int)off1.size() - 1, maxDist, nnRatio, match12.data());
+        if (rc != ORBFE_OK) return rc;
+        // rotation consistency (:236-246, :267-285)
+        const int HISTO_LENGTH = 30;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        const float factor = 1.0f / HISTO_LENGTH;
+        int n = 0;
+        for (int i = 0; i < n1; i++) {
+            if (match12[i] < 0) continue;
+            n++;
+            if (!checkOrientation) continue;
+            float rot = keys1[i].angle - keys2[match12[i]].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(i);
+        }
+        if (checkOrientation) {
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match12[rotHist[i][j]] = -1;
+                    n--;
+                }
+            }
+        }
+        *nmatches = n;
+        return ORBFE_OK;
+    }
+    // ORBmatcher::ComputeThreeMaxima (:1601-1642)
+    static void ComputeThreeMaxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < L; i++) {
+            const int s = (int)histo[i].size();
+            if (s > max1) {
+                max3 = max2; max2 = max1; max1 = s;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (s > max2) {
+                max3 = max2; max2 = s;
+                ind3 = ind2; ind2 = i;
+            } else if (s > max3) {
+                max3 = s;
+                ind3 = i;
+            }
+        }
+        if (max2 < 0.1f * (float)max1) {
+            ind2 = -1;
+            ind3 = -1;
+        } else if (max3 < 0.1f * (float)max1) {
+            ind3 = -1;
+        }
+    }
+
+private:
+    orbfe_matcher *m_;
 };
 
 }  // namespace orbfe

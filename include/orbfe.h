@@ -231,6 +231,19 @@ int orbfe_frame_grid_destroy(orbfe_frame_grid *g);
  * is made; associations made DURING the reference's loop are the caller's to replay).  Synchronous. */
 int orbfe_search_area(orbfe_matcher *m, orbfe_frame_grid *g, const orbfe_area_query *queries, const uint8_t *query_desc, int nq,
                       const uint8_t *blocked, orbfe_area_result *results);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:159-288) and SearchByBoW(KeyFrame*, KeyFrame*, ...)
+ * (:522-655) without the rotation histogram: for every vocabulary node present in both feature vectors (the caller's
+ * merge walk, :180-264, gives node_off / node_idx for both sides in FeatureVector order), each side-1 feature with
+ * valid1 != 0 (MapPoint present and not bad; NULL = all valid) takes the best side-2 feature of the node by the loop at
+ * :205-226 -- side-2 features matched earlier in the call or listed in blocked2 (:574-580; NULL = none) are skipped --
+ * and is matched if bestDist1 <= max_dist (TH_LOW, or TH_LOW - 1 for the strict test at :598) and
+ * (float)bestDist1 < nn_ratio * (float)bestDist2.  match1[i] = matched side-2 index or -1.  The sequential dependency
+ * (:209, :576) stays inside a node because a feature belongs to one node; the device walks each node in order, so the
+ * result is the reference loop's.  Host pointers, synchronous.  include/ORBmatcher_orbfe.h adds the histogram. */
+int orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *desc1, const uint8_t *valid1, int n1, const uint8_t *desc2,
+                        const uint8_t *blocked2, int n2, const int32_t *node_off1, const int32_t *node_idx1,
+                        const int32_t *node_off2, const int32_t *node_idx2, int n_nodes, int max_dist, float nn_ratio,
+                        int32_t *match1);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

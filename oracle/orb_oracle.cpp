@@ -1093,6 +1093,93 @@ void orc_search_area(const orc_grid *g, const uint8_t *kdesc, const float *urigh
     res[6] = bestIdx2;
 }
 
+/* ------------------------------------------------------------ SearchByBoW (src/ORBmatcher.cc:159-288, :522-655) */
+/* The loops over one shared node after the other, as the reference's merge walk visits them; see include/orbfe.h
+ * (orbfe_search_by_bow) for the argument meaning. */
+void orc_search_by_bow(const uint8_t *desc1, const uint8_t *valid1, int n1, const uint8_t *desc2, const uint8_t *blocked2, int n2,
+                       const int32_t *off1, const int32_t *idx1, const int32_t *off2, const int32_t *idx2, int n_nodes,
+                       int max_dist, float nn_ratio, int32_t *match1) {
+    std::vector<char> matched2((size_t)std::max(n2, 1), 0);                     /* vpMapPointMatches[realIdxF] != NULL / vbMatched2 */
+    for (int i = 0; i < n1; i++) match1[i] = -1;
+    for (int k = 0; k < n_nodes; k++) {
+        for (int a = off1[k]; a < off1[k + 1]; a++) {                           /* :187 / :554 */
+            const int realIdx1 = idx1[a];
+            if (valid1 && !valid1[realIdx1]) continue;                          /* :193-197 / :559-562 */
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int b = off2[k]; b < off2[k + 1]; b++) {                       /* :205 / :570 */
+                const int realIdx2 = idx2[b];
+                if (matched2[realIdx2] || (blocked2 && blocked2[realIdx2])) continue;   /* :209 / :576-580 */
+                const int dist = hamming(desc1 + (size_t)realIdx1 * 32, desc2 + (size_t)realIdx2 * 32);
+                if (dist < bestDist1) {
+                    bestDist2 = bestDist1;
+                    bestDist1 = dist;
+                    bestIdx2 = realIdx2;
+                } else if (dist < bestDist2) {
+                    bestDist2 = dist;
+                }
+            }
+            if (bestDist1 <= max_dist) {                                        /* :228 (<= TH_LOW) / :598 (< TH_LOW) */
+                if (static_cast<float>(bestDist1) < nn_ratio * static_cast<float>(bestDist2)) {
+                    match1[realIdx1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                }
+            }
+        }
+    }
+}
+
+/* ComputeThreeMaxima (:1601-1642) on the bin sizes */
+void orc_three_maxima(const int32_t *sizes, int L, int32_t ind[3]) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s; ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1; ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+    ind[0] = ind1; ind[1] = ind2; ind[2] = ind3;
+}
+
+/* the rotation-consistency step (:236-246, :267-285): matches whose angle difference falls outside the three fullest of
+ * the 30 bins are dropped.  Returns the number of matches left. */
+int orc_rotation_filter(const float *angle1, const float *angle2, int32_t *match1, int n1) {
+    const int HISTO_LENGTH = 30;
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) {
+        if (match1[i] < 0) continue;
+        float rot = angle1[i] - angle2[match1[i]];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(i);
+        nmatches++;
+    }
+    int32_t sizes[30], ind[3];
+    for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int32_t)rotHist[i].size();
+    orc_three_maxima(sizes, HISTO_LENGTH, ind);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+        for (int j : rotHist[i]) {
+            match1[j] = -1;
+            nmatches--;
+        }
+    }
+    return nmatches;
+}
+
 /* ------------------------------------------------------------ CPU baseline */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps) {

@@ -122,6 +122,12 @@ int orc_features_in_area(const orc_grid *g, float x, float y, float r, int min_l
  * bestLevel2, number of candidates returned by GetFeaturesInArea} */
 void orc_search_area(const orc_grid *g, const uint8_t *kdesc, const float *uright, const uint8_t *blocked, float x, float y,
                      float r, int min_level, int max_level, float proj_xr, float er_max, const uint8_t *qdesc, int32_t res[7]);
+/* SearchByBoW loops, ComputeThreeMaxima and the rotation-consistency filter (src/ORBmatcher.cc:159-288, :522-655, :1601-1642) */
+void orc_search_by_bow(const uint8_t *desc1, const uint8_t *valid1, int n1, const uint8_t *desc2, const uint8_t *blocked2, int n2,
+                       const int32_t *off1, const int32_t *idx1, const int32_t *off2, const int32_t *idx2, int n_nodes,
+                       int max_dist, float nn_ratio, int32_t *match1);
+void orc_three_maxima(const int32_t *sizes, int L, int32_t ind[3]);
+int orc_rotation_filter(const float *angle1, const float *angle2, int32_t *match1, int n1);
 
 /* time n_frames calls of orc_extract over `threads` threads (one frame per thread at a time); returns seconds */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,

@@ -29,7 +29,7 @@ EXPORTS = [
     "orbfe_stereo_rowband", "orbfe_matcher_synchronize", "orbfe_matcher_stream", "orbfe_extractor_stream",
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
-    "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area",
+    "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -97,6 +97,7 @@ def lib():
                                           C.POINTER(vp)]
     L.orbfe_frame_grid_destroy.argtypes = [vp]
     L.orbfe_search_area.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+    L.orbfe_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]
     L.orbfe_matcher_synchronize.argtypes = [vp]
     L.orbfe_matcher_stream.restype = vp
     L.orbfe_matcher_stream.argtypes = [vp]
@@ -301,6 +302,19 @@ class ORBmatcher:
     def distinctive_device(self, desc_ptr, off_ptr, n_points, max_per_point, best_ptr, sync=True):
         check(self._L.orbfe_distinctive_descriptors(self._h, vp(desc_ptr), vp(off_ptr), n_points, max_per_point, vp(best_ptr),
                                                     1 if sync else 0))
+
+    def search_by_bow(self, desc1, valid1, desc2, blocked2, off1, idx1, off2, idx2, max_dist=None, nn_ratio=None):
+        """SearchByBoW loops of src/ORBmatcher.cc:180-264 / :550-632 over shared nodes (host arrays in, match1 out)."""
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+        b2 = None if blocked2 is None else np.ascontiguousarray(blocked2, np.uint8)
+        o1, i1, o2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
+        match1 = np.zeros(max(len(d1), 1), np.int32)
+        check(self._L.orbfe_search_by_bow(self._h, _np_ptr(d1), None if v1 is None else _np_ptr(v1), len(d1), _np_ptr(d2),
+                                          None if b2 is None else _np_ptr(b2), len(d2), _np_ptr(o1), _np_ptr(i1), _np_ptr(o2),
+                                          _np_ptr(i2), len(o1) - 1, self.TH_LOW if max_dist is None else int(max_dist),
+                                          self.mfNNratio if nn_ratio is None else float(nn_ratio), _np_ptr(match1)))
+        return match1[:len(d1)]
 
     def synchronize(self):
         check(self._L.orbfe_matcher_synchronize(self._h))

@@ -550,4 +550,85 @@ __global__ __launch_bounds__(64) void search_area_kernel(AreaArgs a) {
     a.res[i] = out;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchByBoW (reference src/ORBmatcher.cc:159-288 for KeyFrame / Frame, :522-655 for KeyFrame / KeyFrame): inside a
+// vocabulary node shared by both feature vectors, every side-1 feature with a good MapPoint looks for its best and
+// second-best side-2 feature of that node, skipping side-2 features already matched earlier in the same call (:209,
+// :576).  A feature sits in exactly one node, so that dependency never leaves the node: one wavefront per shared node
+// walks the node's side-1 features in list order, the lanes split the side-2 features, and the matched set lives in an
+// LDS bitmask -- the sequential loop's result, association for association, without any replay.
+//   key = dist << 16 | position in the node's side-2 list: the smallest key is the first minimum of the list scan (strict
+//   '<'), the second smallest key carries the second-smallest distance of the multiset (the reference's bestDist2).
+struct BowMatchArgs {
+    const uint4 *desc1;          // [n1][2]
+    const uint8_t *valid1;       // [n1] or null: MapPoint present and not bad (:191-197, :558-562)
+    const uint4 *desc2;          // [n2][2]
+    const uint8_t *blocked2;     // [n2] or null: side-2 features that never take part (:574-580)
+    const int32_t *off1, *idx1;  // per shared node: side-1 feature indices (FeatureVector order)
+    const int32_t *off2, *idx2;  // per shared node: side-2 feature indices
+    int nNodes;
+    int maxDist;                 // accept bestDist1 <= maxDist (TH_LOW for :228, TH_LOW - 1 for the strict test at :598)
+    float nnRatio;
+    int32_t *match1;             // [n1], preset to -1: the side-2 feature a side-1 feature was matched to
+};
+
+constexpr int kBowMaxNodeFeatures = 65536;   // side-2 features of one node (LDS bitmask; 16-bit list positions)
+
+__global__ __launch_bounds__(64) void bow_match_kernel(BowMatchArgs a) {
+    __shared__ uint32_t sTaken[kBowMaxNodeFeatures / 32];
+    const int node = blockIdx.x, lane = threadIdx.x;
+    const int b1 = a.off1[node], e1 = a.off1[node + 1], b2 = a.off2[node], e2 = a.off2[node + 1];
+    const int n2 = e2 - b2;
+    if (n2 <= 0 || e1 <= b1) return;
+    for (int wI = lane; wI * 32 < n2; wI += 64) {          // side-2 features excluded from the start
+        uint32_t bits = 0;
+        if (a.blocked2)
+            for (int k = 0; k < 32 && wI * 32 + k < n2; k++) bits |= (a.blocked2[a.idx2[b2 + wI * 32 + k]] ? 1u : 0u) << k;
+        sTaken[wI] = bits;
+    }
+    __syncthreads();
+    // the first 64 side-2 descriptors stay in registers (most nodes hold fewer)
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    if (lane < n2) {
+        const int j = a.idx2[b2 + lane];
+        c0 = a.desc2[2 * (size_t)j]; c1 = a.desc2[2 * (size_t)j + 1];
+    }
+    for (int i = b1; i < e1; i++) {                        // the reference's loop over vIndicesKF, in order
+        const int q = a.idx1[i];
+        if (a.valid1 && !a.valid1[q]) continue;
+        const uint4 q0 = a.desc1[2 * (size_t)q], q1 = a.desc1[2 * (size_t)q + 1];
+        uint32_t best = (256u << 16) | 0xFFFFu, second = best;
+        for (int base = 0; base < n2; base += 64) {
+            const int pos = base + lane;
+            if (pos < n2 && !((sTaken[pos >> 5] >> (pos & 31)) & 1u)) {
+                uint4 d0 = c0, d1 = c1;
+                if (base) {
+                    const int j = a.idx2[b2 + pos];
+                    d0 = a.desc2[2 * (size_t)j]; d1 = a.desc2[2 * (size_t)j + 1];
+                }
+                const uint32_t dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                                      __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+                const uint32_t key = (dist << 16) | (uint32_t)pos;
+                second = min(second, max(best, key));
+                best = min(best, key);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                 // two smallest keys of the wave
+            const uint32_t ob = (uint32_t)__shfl_xor((int)best, o), os = (uint32_t)__shfl_xor((int)second, o);
+            second = min(min(second, os), max(best, ob));
+            best = min(best, ob);
+        }
+        const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(second >> 16), bestPos = (int)(best & 0xFFFFu);
+        if (bestDist1 <= a.maxDist && (float)bestDist1 < __fmul_rn(a.nnRatio, (float)bestDist2)) {   // :228-230 / :598-600
+            if (lane == 0) {
+                sTaken[bestPos >> 5] |= 1u << (bestPos & 31);
+                a.match1[q] = a.idx2[b2 + bestPos];
+            }
+        }
+        __syncthreads();                                   // one wave per workgroup: orders the LDS update before the next scan
+    }
+}
+
 }  // namespace orbfe

@@ -4,6 +4,9 @@
 //                                                          adapter_main stereo left.raw right.raw w h nfeatures bf b out.bin
 //                                                          adapter_main bow voc.txt desc.raw n levelsup out.bin
 //                                                          adapter_main project case.bin out.bin
+//                                                          adapter_main bowmatch case.bin out.bin
+// The bowmatch mode runs orbfe::BowMatcher::SearchByBoW (src/ORBmatcher.cc:159-288 / :522-655) on two feature sets with
+// their FeatureVectors read from case.bin (layout in tests/test_gpu_adapter.py).
 // The project mode replays ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (src/ORBmatcher.cc:45-129) on a frame
 // and a list of projected map points read from case.bin (layout in tests/test_gpu_adapter.py).
 // The bow mode loads a vocabulary in the ORBvoc.txt format and runs Frame::ComputeBoW's transform (src/Frame.cc:395-402).
@@ -123,7 +126,47 @@ static int project_main(char **argv) {
     return 0;
 }
 
+static int bowmatch_main(char **argv) {
+    FILE *fi = std::fopen(argv[2], "rb");
+    if (!fi) return 3;
+    int hdr[6];   // n1, n2, number of (node, feature) entries on side 1 and 2, maxDist, checkOrientation
+    float ratio = 0;
+    if (std::fread(hdr, 4, 6, fi) != 6 || std::fread(&ratio, 4, 1, fi) != 1) return 3;
+    const int n1 = hdr[0], n2 = hdr[1], e1 = hdr[2], e2 = hdr[3];
+    std::vector<unsigned char> d1((size_t)n1 * 32 + 1), d2((size_t)n2 * 32 + 1), valid1(n1), blocked2(n2);
+    std::vector<float> ang1(n1), ang2(n2);
+    std::vector<int> ent1((size_t)e1 * 2 + 1), ent2((size_t)e2 * 2 + 1);   // (node id, feature index) in insertion order
+    auto rd = [&](void *p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, fi) == bytes; };
+    const bool ok = rd(d1.data(), (size_t)n1 * 32) && rd(d2.data(), (size_t)n2 * 32) && rd(valid1.data(), n1) && rd(blocked2.data(), n2) &&
+                    rd(ang1.data(), 4 * (size_t)n1) && rd(ang2.data(), 4 * (size_t)n2) && rd(ent1.data(), 8 * (size_t)e1) &&
+                    rd(ent2.data(), 8 * (size_t)e2);
+    std::fclose(fi);
+    if (!ok) return 3;
+    orbfe::BowMatcher::FeatureVector fv1, fv2;
+    for (int i = 0; i < e1; i++) fv1[(unsigned)ent1[2 * i]].push_back((unsigned)ent1[2 * i + 1]);   // FeatureVector::addFeature
+    for (int i = 0; i < e2; i++) fv2[(unsigned)ent2[2 * i]].push_back((unsigned)ent2[2 * i + 1]);
+    std::vector<cv::KeyPoint> k1(n1), k2(n2);
+    for (int i = 0; i < n1; i++) k1[i].angle = ang1[i];
+    for (int i = 0; i < n2; i++) k2[i].angle = ang2[i];
+    cv::Mat D1(n1, 32, CV_8UC1, d1.data(), (size_t)32), D2(n2, 32, CV_8UC1, d2.data(), (size_t)32);
+    orbfe::BowMatcher bm;
+    std::vector<int> match12;
+    int nmatches = 0;
+    if (bm.SearchByBoW(fv1, D1, k1, valid1, fv2, D2, k2, blocked2, hdr[4], ratio, hdr[5] != 0, match12, &nmatches) != 0) {
+        std::fprintf(stderr, "bowmatch: %s\n", orbfe_last_error());
+        return 6;
+    }
+    FILE *fo = std::fopen(argv[3], "wb");
+    if (!fo) return 4;
+    std::fwrite(&nmatches, 4, 1, fo);
+    std::fwrite(match12.data(), 4, n1, fo);
+    std::fclose(fo);
+    std::printf("adapter bowmatch ok: %d x %d features, %d matches\n", n1, n2, nmatches);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 4 && std::strcmp(argv[1], "bowmatch") == 0) return bowmatch_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "project") == 0) return project_main(argv);
     if (argc >= 7 && std::strcmp(argv[1], "bow") == 0) return bow_main(argv);
     if (argc >= 10 && std::strcmp(argv[1], "stereo") == 0) return stereo_main(argv);

@@ -45,6 +45,8 @@ def oracle_digests():
     rows = [og.search(float(aq["x"][i]), float(aq["y"][i]), float(aq["r"][i]), int(aq["min_level"][i]), int(aq["max_level"][i]),
                       float(aq["proj_xr"][i]), float(aq["er_max"][i]), qd[i], blocked) for i in range(len(qd))]
     out["search_area"] = G.area_digest(np.array(rows, np.int32))
+    d1, v1, d2, b2, (o1, i1), (o2, i2) = G.bowmatch_inputs()
+    out["search_by_bow"] = G.bowmatch_digest(O.search_by_bow(d1, v1, d2, b2, o1, i1, o2, i2, G.BOWMATCH["max_dist"], G.BOWMATCH["ratio"]))
     return out
 
 

@@ -27,6 +27,7 @@ KNN = dict(nq=300, nr=5000, seed=16)
 BOW = dict(k=10, L=4, seed=17, n=3000, levelsup=2)
 DISTINCTIVE = dict(seed=18, points=400)
 AREA = dict(seed=19, nq=800)
+BOWMATCH = dict(seed=20, n1=1200, n2=1500, nodes=90, max_dist=50, ratio=0.7)
 
 
 def crc(a) -> int:
@@ -144,6 +145,33 @@ def area_digest(rows):
     """rows: int32 [nq, 7] = best_dist, best_idx, best_level, best_dist2, best_level2, n_candidates, best_idx2"""
     rows = np.asarray(rows, np.int32)
     return {"sha256": sha(rows), "first_8": rows[:8].tolist(), "with_match": int((rows[:, 1] >= 0).sum())}
+
+
+def bowmatch_inputs():
+    c = BOWMATCH
+    rng = np.random.default_rng(c["seed"])
+    d2 = synth.random_descriptors(c["n2"], 6000 + c["seed"])
+    src = rng.integers(0, c["n2"], c["n1"])
+    d1 = d2[src].copy()
+    for i in range(c["n1"]):
+        for b in rng.integers(0, 256, int(rng.integers(0, 40))):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    node2 = rng.integers(0, c["nodes"], c["n2"])
+    node1 = node2[src].copy()
+    stray = rng.uniform(size=c["n1"]) < 0.1
+    node1[stray] = rng.integers(0, c["nodes"], int(stray.sum()))
+
+    def csr(node):
+        order = [np.nonzero(node == k)[0] for k in range(c["nodes"])]
+        return (np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32), np.concatenate(order).astype(np.int32))
+    valid1 = (rng.uniform(size=c["n1"]) < 0.85).astype(np.uint8)
+    blocked2 = (rng.uniform(size=c["n2"]) < 0.1).astype(np.uint8)
+    return d1, valid1, d2, blocked2, csr(node1), csr(node2)
+
+
+def bowmatch_digest(match1):
+    match1 = np.asarray(match1, np.int32)
+    return {"sha256": sha(match1), "matches": int((match1 >= 0).sum()), "first_16": match1[:16].tolist()}
 
 
 def load():

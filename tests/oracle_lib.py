@@ -74,6 +74,12 @@ def lib():
         L.orc_search_area.argtypes = [C.c_void_p, u8p, f32p, u8p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                                       C.c_float, u8p, i32p]
         L.orc_search_area.restype = None
+        L.orc_search_by_bow.argtypes = [u8p, u8p, C.c_int, u8p, u8p, C.c_int, i32p, i32p, i32p, i32p, C.c_int, C.c_int, C.c_float, i32p]
+        L.orc_search_by_bow.restype = None
+        L.orc_three_maxima.argtypes = [i32p, C.c_int, i32p]
+        L.orc_three_maxima.restype = None
+        L.orc_rotation_filter.argtypes = [f32p, f32p, i32p, C.c_int]
+        L.orc_rotation_filter.restype = C.c_int
         L.orc_distinctive.argtypes = [u8p, i32p, C.c_int, i32p]
         L.orc_distinctive.restype = None
         L.orc_bow_descend.argtypes = [i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p, i32p]
@@ -335,6 +341,33 @@ class OracleGrid:
                               None if b is None else _ptr(b, u8p), x, y, r, min_level, max_level, proj_xr, er_max, _ptr(q, u8p),
                               _ptr(res, i32p))
         return res
+
+
+def search_by_bow(desc1, valid1, desc2, blocked2, off1, idx1, off2, idx2, max_dist, nn_ratio):
+    """SearchByBoW loops (src/ORBmatcher.cc:180-264 / :550-632) over the shared nodes given as two CSR lists."""
+    d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    b2 = None if blocked2 is None else np.ascontiguousarray(blocked2, np.uint8)
+    o1, i1, o2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
+    match1 = np.zeros(max(len(d1), 1), np.int32)
+    lib().orc_search_by_bow(_ptr(d1, u8p), None if v1 is None else _ptr(v1, u8p), len(d1), _ptr(d2, u8p),
+                            None if b2 is None else _ptr(b2, u8p), len(d2), _ptr(o1, i32p), _ptr(i1, i32p), _ptr(o2, i32p),
+                            _ptr(i2, i32p), len(o1) - 1, max_dist, nn_ratio, _ptr(match1, i32p))
+    return match1[:len(d1)]
+
+
+def three_maxima(sizes):
+    s = np.ascontiguousarray(sizes, np.int32)
+    ind = np.zeros(3, np.int32)
+    lib().orc_three_maxima(_ptr(s, i32p), len(s), _ptr(ind, i32p))
+    return ind.tolist()
+
+
+def rotation_filter(angle1, angle2, match1):
+    a1, a2 = np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(angle2, np.float32)
+    m = np.ascontiguousarray(match1, np.int32).copy()
+    n = lib().orc_rotation_filter(_ptr(a1, f32p), _ptr(a2, f32p), _ptr(m, i32p), len(m))
+    return m, n
 
 
 def time_extract(frames: np.ndarray, nfeatures, scale_factor, nlevels, ini_th, min_th, threads, reps=1):

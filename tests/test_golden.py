@@ -1,7 +1,7 @@
 """Committed golden fixtures (tests/golden/front_end.json, written by tests/golden/make_golden.py from the oracle).
 CPU: the oracle still reproduces them.  GPU: liborbfe, through the C-ABI, produces the same digests with no oracle in
 the loop -- pyramid and blurred levels, FAST candidates, keypoints, descriptors, stereo depths, kNN-2, BoW descent,
-distinctive descriptors and windowed search, all bit-exact (SHA-256 / CRC32 of the raw outputs)."""
+distinctive descriptors, windowed search and the SearchByBoW loops, all bit-exact (SHA-256 / CRC32 of the raw outputs)."""
 import importlib.util
 from pathlib import Path
 
@@ -27,7 +27,7 @@ def _diff(got, want, path=""):
 
 def test_golden_file_is_complete():
     g = G.load()
-    assert sorted(g) == ["bow_descend", "distinctive", "extract", "knn2", "search_area", "stereo"]
+    assert sorted(g) == ["bow_descend", "distinctive", "extract", "knn2", "search_area", "search_by_bow", "stereo"]
     assert sorted(g["extract"]) == sorted(G.EXTRACT_CASES)
     k = g["extract"]["kitti_1241x376_2000"]
     # SURVEY.md section 8a check values: level sizes of 1241x376 at scale 1.2
@@ -110,3 +110,7 @@ def test_hip_path_reproduces_golden():
     rows = np.stack([res[fld] for fld in ("best_dist", "best_idx", "best_level", "best_dist2", "best_level2", "n_candidates",
                                           "best_idx2")], axis=1)
     _diff(G.area_digest(rows), want["search_area"], "search_area")
+    # SearchByBoW loops
+    d1, v1, d2, b2, (o1, i1), (o2, i2) = G.bowmatch_inputs()
+    got = m.search_by_bow(d1, v1, d2, b2, o1, i1, o2, i2, G.BOWMATCH["max_dist"], G.BOWMATCH["ratio"])
+    _diff(G.bowmatch_digest(got), want["search_by_bow"], "search_by_bow")

@@ -162,3 +162,57 @@ def test_cpp_projection_search_replays_the_reference_loop(tmp_path):
     assert np.array_equal(match_idx, want)
     assert nmatches == (want >= 0).sum() and np.array_equal(occ_out, blocked)
     assert nmatches > 500 and requeried > 10                     # contention really occurred and was replayed
+
+
+@pytest.mark.parametrize("max_dist,check_ori", [(50, True), (49, True), (50, False)])
+def test_cpp_bow_matcher_matches_oracle(tmp_path, max_dist, check_ori):
+    """orbfe::BowMatcher::SearchByBoW (include/ORBmatcher_orbfe.h): merge walk over two DBoW2-style FeatureVectors, device
+    loops, rotation histogram + ComputeThreeMaxima == the oracle's restatement of src/ORBmatcher.cc:159-288 / :522-655."""
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    assert exe.exists()
+    rng = np.random.default_rng(77 + max_dist)
+    n1, n2 = 1800, 2000
+    d2 = synth.random_descriptors(n2, 314)
+    src = rng.integers(0, n2, n1)
+    d1 = d2[src].copy()
+    for i in range(n1):
+        for b in rng.integers(0, 256, int(rng.integers(0, 40))):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    # node ids: sparse and different on both sides, so the merge walk has to skip (lower_bound branches)
+    node2 = rng.integers(0, 120, n2) * 7
+    node1 = node2[src].copy()
+    stray = rng.uniform(size=n1) < 0.15
+    node1[stray] = rng.integers(0, 900, int(stray.sum()))
+    ang2 = rng.uniform(0, 360, n2).astype(np.float32)
+    # most true matches share one rotation (the camera rolled by ~20 degrees); the rest are spread: the histogram removes them
+    ang1 = np.where(rng.uniform(size=n1) < 0.8, ang2[src] + 20 + rng.normal(0, 3, n1), rng.uniform(0, 360, n1)).astype(np.float32)
+    ang1 = np.mod(ang1, np.float32(360)).astype(np.float32)
+    valid1 = (rng.uniform(size=n1) < 0.9).astype(np.uint8)
+    blocked2 = (rng.uniform(size=n2) < 0.05).astype(np.uint8)
+    ent1 = np.stack([node1, np.arange(n1)], 1).astype(np.int32)      # features are added in index order (FeatureVector::addFeature)
+    ent2 = np.stack([node2, np.arange(n2)], 1).astype(np.int32)
+    case, out = tmp_path / "case.bin", tmp_path / "out.bin"
+    with open(case, "wb") as fh:
+        fh.write(np.array([n1, n2, n1, n2, max_dist, int(check_ori)], np.int32).tobytes())
+        fh.write(np.array([0.7], np.float32).tobytes())
+        for a in (d1, d2, valid1, blocked2, ang1, ang2, ent1, ent2):
+            fh.write(np.ascontiguousarray(a).tobytes())
+    r = subprocess.run([str(exe), "bowmatch", str(case), str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    nmatches = int(np.frombuffer(buf, np.int32, 1)[0])
+    match12 = np.frombuffer(buf, np.int32, n1, 4)
+    # reference: std::map order = ascending node id, features of a node in insertion order; shared nodes only
+    shared = sorted(set(node1.tolist()) & set(node2.tolist()))
+    l1 = [np.nonzero(node1 == k)[0] for k in shared]
+    l2 = [np.nonzero(node2 == k)[0] for k in shared]
+    off1 = np.concatenate([[0], np.cumsum([len(x) for x in l1])]).astype(np.int32)
+    off2 = np.concatenate([[0], np.cumsum([len(x) for x in l2])]).astype(np.int32)
+    ref = O.search_by_bow(d1, valid1, d2, blocked2, off1, np.concatenate(l1), off2, np.concatenate(l2), max_dist, 0.7)
+    before = int((ref >= 0).sum())
+    if check_ori:
+        ref, n_ref = O.rotation_filter(ang1, ang2, ref)
+    else:
+        n_ref = before
+    assert np.array_equal(match12, ref) and nmatches == n_ref
+    assert n_ref > 300 and (not check_ori or n_ref < before)        # the histogram really removed something

@@ -292,3 +292,57 @@ def test_search_area_matches_oracle():
     # the case is not vacuous: most queries find something even with 20 % of the keypoints blocked and the stereo
     # gate on half of them, and a good share of the windows hold several candidates
     assert (res["best_idx"] >= 0).mean() > 0.5 and (res["n_candidates"] > 3).mean() > 0.15
+
+
+def _bow_case(rng, n1, n2, nn, noise_bits=40, shuffle=True):
+    """Two feature sets sharing vocabulary nodes: side 1 = noisy copies of side-2 features (several may want the same one)."""
+    d2 = synth.random_descriptors(n2, int(rng.integers(1, 1 << 30)))
+    src = rng.integers(0, n2, n1)
+    d1 = d2[src].copy()
+    for i in range(n1):
+        for b in rng.integers(0, 256, int(rng.integers(0, noise_bits))):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    node2 = rng.integers(0, nn, n2)
+    node1 = node2[src].copy()
+    wrong = rng.uniform(size=n1) < 0.1
+    node1[wrong] = rng.integers(0, nn, int(wrong.sum()))
+
+    def csr(node):
+        order = [np.nonzero(node == k)[0] for k in range(nn)]
+        if shuffle:
+            for o in order:
+                rng.shuffle(o)
+        return (np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32),
+                np.concatenate(order).astype(np.int32))
+    return d1, d2, csr(node1), csr(node2)
+
+
+@pytest.mark.parametrize("n1,n2,nn", [(1500, 2000, 100), (300, 5000, 3), (2000, 2000, 1), (50, 40, 200), (1000, 1200, 1000)])
+def test_search_by_bow_matches_oracle(n1, n2, nn):
+    """a-11: the SearchByBoW loops (src/ORBmatcher.cc:180-264, :550-632) on the device, one wavefront per shared node;
+    includes nodes with more than 64 side-2 features, a single node holding everything, empty nodes, both threshold forms."""
+    rng = np.random.default_rng(n1 + n2 + nn)
+    d1, d2, (off1, idx1), (off2, idx2) = _bow_case(rng, n1, n2, nn)
+    valid1 = (rng.uniform(size=n1) < 0.85).astype(np.uint8)
+    blocked2 = (rng.uniform(size=n2) < 0.1).astype(np.uint8)
+    m = capi.ORBmatcher()
+    total = 0
+    for v1, b2, md, ratio in ((valid1, None, 50, 0.7), (valid1, blocked2, 49, 0.75), (None, None, 100, 0.9), (None, blocked2, 50, 0.6)):
+        got = m.search_by_bow(d1, v1, d2, b2, off1, idx1, off2, idx2, md, ratio)
+        ref = O.search_by_bow(d1, v1, d2, b2, off1, idx1, off2, idx2, md, ratio)
+        assert np.array_equal(got, ref), (md, ratio)
+        total += int((ref >= 0).sum())
+    assert total > 20
+
+
+def test_search_by_bow_argument_errors():
+    m = capi.ORBmatcher()
+    d = synth.random_descriptors(4, 1)
+    ok_off, ok_idx = np.array([0, 4], np.int32), np.arange(4, dtype=np.int32)
+    assert (m.search_by_bow(d, None, d[:0], None, ok_off, ok_idx, np.array([0, 0], np.int32), ok_idx[:0], 50, 0.7) == -1).all()
+    with pytest.raises(capi.OrbfeError):       # an index past the descriptor array must be refused on the host, not fault on the GPU
+        m.search_by_bow(d, None, d, None, ok_off, np.array([0, 1, 2, 4], np.int32), ok_off, ok_idx, 50, 0.7)
+    with pytest.raises(capi.OrbfeError):
+        m.search_by_bow(d, None, d, None, np.array([0, 5], np.int32), ok_idx, ok_off, ok_idx, 50, 0.7)
+    with pytest.raises(capi.OrbfeError):
+        m.search_by_bow(d, None, d, None, np.array([1, 4], np.int32), ok_idx, ok_off, ok_idx, 50, 0.7)

@@ -699,3 +699,76 @@ def test_search_area_result_depends_only_on_its_two_holders():
             else:
                 changed_by_holder += after.tolist() != base.tolist()
     assert changed_by_holder > 20
+
+
+def _bow_brute(desc1, valid1, desc2, blocked2, off1, idx1, off2, idx2, max_dist, ratio):
+    """numpy restatement of the SearchByBoW loops, written independently of the oracle's C++ (sorting instead of scanning)."""
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    taken = np.zeros(len(desc2), bool) if blocked2 is None else np.asarray(blocked2, bool).copy()
+    match1 = np.full(len(desc1), -1, np.int32)
+    for k in range(len(off1) - 1):
+        for a in idx1[off1[k]:off1[k + 1]]:
+            if valid1 is not None and not valid1[a]:
+                continue
+            cand = [int(b) for b in idx2[off2[k]:off2[k + 1]] if not taken[b]]
+            if not cand:
+                continue
+            d = pop[desc1[a][None, :] ^ desc2[cand]].sum(1)
+            order = np.argsort(d, kind="stable")                    # first minimum = first in list order
+            best, second = int(d[order[0]]), (int(d[order[1]]) if len(cand) > 1 else 256)
+            if best <= max_dist and np.float32(best) < np.float32(ratio) * np.float32(second):
+                match1[a] = cand[order[0]]
+                taken[cand[order[0]]] = True
+    return match1
+
+
+def test_search_by_bow_oracle_vs_numpy():
+    rng = np.random.default_rng(41)
+    n1, n2, nn = 600, 700, 40
+    d2 = synth.random_descriptors(n2, 5)
+    src = rng.integers(0, n2, n1)
+    d1 = d2[src].copy()                                             # side 1 = noisy copies of side-2 features: real matches,
+    for i in range(n1):                                             # several side-1 features competing for one side-2 feature
+        for b in rng.integers(0, 256, int(rng.integers(0, 40))):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    node2 = rng.integers(0, nn, n2)
+    node1 = node2[src]
+    node1[:50] = rng.integers(0, nn, 50)                            # some features in the wrong node
+    def csr(node, n):
+        order = [np.nonzero(node == k)[0] for k in range(nn)]
+        for o in order:
+            rng.shuffle(o)                                          # FeatureVector order is insertion order, not sorted
+        return np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32), np.concatenate(order).astype(np.int32)
+    off1, idx1 = csr(node1, n1)
+    off2, idx2 = csr(node2, n2)
+    valid1 = (rng.uniform(size=n1) < 0.8).astype(np.uint8)
+    blocked2 = (rng.uniform(size=n2) < 0.1).astype(np.uint8)
+    for v1, b2, md, ratio in ((valid1, None, 50, 0.7), (valid1, blocked2, 49, 0.75), (None, None, 100, 0.9)):
+        got = O.search_by_bow(d1, v1, d2, b2, off1, idx1, off2, idx2, md, ratio)
+        want = _bow_brute(d1, v1, d2, b2, off1, idx1, off2, idx2, md, ratio)
+        assert np.array_equal(got, want)
+        m = got[got >= 0]
+        assert len(m) > 100 and len(np.unique(m)) == len(m)         # a side-2 feature is matched at most once
+
+
+def test_three_maxima_and_rotation_filter():
+    """ComputeThreeMaxima (src/ORBmatcher.cc:1601-1642): strict '>' updates, the 10 % rule; then the histogram filter."""
+    assert O.three_maxima([0] * 30) == [-1, -1, -1]
+    s = [0] * 30
+    s[4], s[9], s[2] = 10, 7, 7                                     # equal sizes: the earlier bin stays ahead
+    assert O.three_maxima(s) == [4, 2, 9]
+    s = [0] * 30
+    s[1], s[5], s[7] = 100, 9, 50                                   # third below 10 % of the first: dropped
+    assert O.three_maxima(s) == [1, 7, -1]
+    s = [0] * 30
+    s[3], s[8] = 100, 9                                             # second below 10 %: second and third dropped
+    assert O.three_maxima(s) == [3, -1, -1]
+    # rotation filter: bin = round(rot * (1/30)), half away from zero.  Differences 1..4 and 14.9 -> bin 0 (5 matches),
+    # 45..47 -> 1.5.. -> bin 2 (3), 100, 101 -> bin 3 (2), 200 -> bin 7 (1), 359 -> bin 12 (1): bins 0, 2, 3 survive.
+    a2 = np.zeros(12, np.float32)
+    a1 = np.array([1, 2, 3, 4, 45, 46, 47, 100, 101, 200, 359, 14.9], np.float32)
+    m, n = O.rotation_filter(a1, a2, np.arange(12))
+    assert n == 10 and m.tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, -1, -1, 11]
+    # negative differences wrap by +360: -10 -> 350 -> bin 12; unmatched entries stay out of the histogram
+    m, n = O.rotation_filter(np.array([0, 0, 0], np.float32), np.array([10, 10, 0], np.float32), np.array([0, 1, -1]))
+    assert n == 2 and m.tolist() == [0, 1, -1]
