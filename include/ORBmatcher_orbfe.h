@@ -128,11 +128,47 @@ private:
 // call is made; the loop's own assignments (:123) are then replayed on the host in the reference's order, and a query
 // whose best or second keypoint was taken by an earlier MapPoint of the same call is searched again, alone, against the
 // updated state -- so the outcome is the sequential loop's, association for association.
+// ORBmatcher::ComputeThreeMaxima (:1601-1642)
+inline void three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
 struct ProjectedPoint {
     float projX, projY, projXR;   // mTrackProjX, mTrackProjY, mTrackProjXR
     int level;                    // mnTrackScaleLevel
     float viewCos;                // mTrackViewCos
     const unsigned char *desc;    // GetDescriptor(): 32 bytes
+    bool observed = true;         // pMP->Observations() > 0: only then does its keypoint block later MapPoints (:87-89)
+};
+// One LastFrame MapPoint of SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (:1328-1470), after
+// the projection the reference computes on the host (:1360-1381).
+struct TrackedPoint {
+    float u, v;                   // :1370-1371
+    float ur;                     // u - mbf * invzc (:1409)
+    float radius;                 // th * mvScaleFactors[nLastOctave] (:1381)
+    int minLevel, maxLevel;       // :1385-1390: (oct, -1) forward, (0, oct) backward, (oct - 1, oct + 1) otherwise
+    float angle;                  // LastFrame.mvKeysUn[i].angle
+    const unsigned char *desc;    // pMP->GetDescriptor()
+    bool observed;                // pMP->Observations() > 0 (false for the temporal points of UpdateLastFrame)
 };
 class ProjectionSearch {
 public:
@@ -199,12 +235,84 @@ public:
             }
             if (r.best_dist <= 100) {                                          // TH_HIGH, :118
                 if (r.best_level == r.best_level2 && r.best_dist > nnRatio * r.best_dist2) continue;   // :120
-                occupied[r.best_idx] = 1;                                      // :123
-                taken[r.best_idx] = 1;
+                if (pts[i].observed) {                                         // :123, seen by :87-89 of later MapPoints
+                    occupied[r.best_idx] = 1;
+                    taken[r.best_idx] = 1;
+                }
                 matchIdx[i] = r.best_idx;
                 (*nmatches)++;
             }
         }
+        return ORBFE_OK;
+    }
+    // SearchByProjection(CurrentFrame, LastFrame, th, bMono) (:1328-1470) from the window search on: best match only,
+    // accepted up to TH_HIGH, then the rotation histogram.  build() was called with CurrentFrame's members; curAngles =
+    // CurrentFrame.mvKeysUn[*].angle; occupied as in search().  assigned[idx] = index into pts of the MapPoint that
+    // CurrentFrame.mvpMapPoints[idx] ends up with, or -1 (a keypoint taken by an unobserved MapPoint can be overwritten by
+    // a later one, as in the reference); *nmatches is the reference's return value (it counts such a keypoint twice).
+    int searchLastFrame(const std::vector<TrackedPoint> &pts, const std::vector<float> &curAngles, bool checkOrientation,
+                        std::vector<unsigned char> &occupied, std::vector<int> &assigned, int *nmatches) {
+        const int nq = (int)pts.size();
+        assigned.assign(n_, -1);
+        *nmatches = 0;
+        if (nq == 0 || n_ == 0) return ORBFE_OK;
+        if ((int)occupied.size() != n_ || (int)curAngles.size() != n_) return ORBFE_ERR_ARG;
+        std::vector<orbfe_area_query> q(nq);
+        std::vector<unsigned char> qd((size_t)nq * 32);
+        for (int i = 0; i < nq; i++) {
+            q[i].x = pts[i].u;
+            q[i].y = pts[i].v;
+            q[i].r = pts[i].radius;
+            q[i].min_level = pts[i].minLevel;
+            q[i].max_level = pts[i].maxLevel;
+            q[i].proj_xr = pts[i].ur;
+            q[i].er_max = pts[i].radius;                                       // :1411
+            q[i].pad = 0;
+            for (int b = 0; b < 32; b++) qd[(size_t)i * 32 + b] = pts[i].desc[b];
+        }
+        std::vector<orbfe_area_result> res(nq);
+        int rc = orbfe_search_area(m_, g_, q.data(), qd.data(), nq, occupied.data(), res.data());
+        if (rc != ORBFE_OK) return rc;
+        const int HISTO_LENGTH = 30;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        const float factor = 1.0f / HISTO_LENGTH;
+        std::vector<unsigned char> taken(n_, 0);
+        int n = 0;
+        for (int i = 0; i < nq; i++) {
+            orbfe_area_result r = res[i];
+            if (r.best_idx >= 0 && taken[r.best_idx]) {                        // only the best match is used here
+                rc = orbfe_search_area(m_, g_, &q[i], &qd[(size_t)i * 32], 1, occupied.data(), &r);
+                if (rc != ORBFE_OK) return rc;
+                requeried_++;
+            }
+            if (r.best_dist > 100) continue;                                   // TH_HIGH, :1426 (covers vIndices2.empty())
+            assigned[r.best_idx] = i;                                          // :1428
+            n++;
+            if (pts[i].observed) {
+                occupied[r.best_idx] = 1;
+                taken[r.best_idx] = 1;
+            }
+            if (checkOrientation) {                                            // :1431-1441
+                float rot = pts[i].angle - curAngles[r.best_idx];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(r.best_idx);
+            }
+        }
+        if (checkOrientation) {                                                // :1448-1467
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    assigned[rotHist[i][j]] = -1;
+                    occupied[rotHist[i][j]] = 0;
+                    n--;
+                }
+            }
+        }
+        *nmatches = n;
         return ORBFE_OK;
     }
     long requeried() const { return requeried_; }
@@ -291,28 +399,8 @@ public:
         *nmatches = n;
         return ORBFE_OK;
     }
-    // ORBmatcher::ComputeThreeMaxima (:1601-1642)
     static void ComputeThreeMaxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
-        int max1 = 0, max2 = 0, max3 = 0;
-        for (int i = 0; i < L; i++) {
-            const int s = (int)histo[i].size();
-            if (s > max1) {
-                max3 = max2; max2 = max1; max1 = s;
-                ind3 = ind2; ind2 = ind1; ind1 = i;
-            } else if (s > max2) {
-                max3 = max2; max2 = s;
-                ind3 = ind2; ind2 = i;
-            } else if (s > max3) {
-                max3 = s;
-                ind3 = i;
-            }
-        }
-        if (max2 < 0.1f * (float)max1) {
-            ind2 = -1;
-            ind3 = -1;
-        } else if (max3 < 0.1f * (float)max1) {
-            ind3 = -1;
-        }
+        three_maxima(histo, L, ind1, ind2, ind3);
     }
 
 private:

@@ -5,6 +5,9 @@
 //                                                          adapter_main bow voc.txt desc.raw n levelsup out.bin
 //                                                          adapter_main project case.bin out.bin
 //                                                          adapter_main bowmatch case.bin out.bin
+//                                                          adapter_main track case.bin out.bin
+// The track mode runs orbfe::ProjectionSearch::searchLastFrame: SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+// (src/ORBmatcher.cc:1328-1470) from the window search on.
 // The bowmatch mode runs orbfe::BowMatcher::SearchByBoW (src/ORBmatcher.cc:159-288 / :522-655) on two feature sets with
 // their FeatureVectors read from case.bin (layout in tests/test_gpu_adapter.py).
 // The project mode replays ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (src/ORBmatcher.cc:45-129) on a frame
@@ -126,6 +129,55 @@ static int project_main(char **argv) {
     return 0;
 }
 
+static int track_main(char **argv) {
+    FILE *fi = std::fopen(argv[2], "rb");
+    if (!fi) return 3;
+    int n = 0, nq = 0, checkOri = 0;
+    float f[4];
+    if (std::fread(&n, 4, 1, fi) != 1 || std::fread(&nq, 4, 1, fi) != 1 || std::fread(&checkOri, 4, 1, fi) != 1 ||
+        std::fread(f, 4, 4, fi) != 4 || n < 0 || nq < 0)
+        return 3;
+    std::vector<float> kx(n), ky(n), kur(n), kang(n), pu(nq), pv(nq), pur(nq), prad(nq), pang(nq);
+    std::vector<int> oct(n), pmin(nq), pmax(nq);
+    std::vector<unsigned char> desc((size_t)n * 32 + 1), occ(n), pobs(nq), qd((size_t)nq * 32 + 1);
+    auto rd = [&](void *p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, fi) == bytes; };
+    const bool ok = rd(kx.data(), 4 * (size_t)n) && rd(ky.data(), 4 * (size_t)n) && rd(oct.data(), 4 * (size_t)n) && rd(kur.data(), 4 * (size_t)n) &&
+                    rd(kang.data(), 4 * (size_t)n) && rd(desc.data(), 32 * (size_t)n) && rd(occ.data(), (size_t)n) && rd(pu.data(), 4 * (size_t)nq) &&
+                    rd(pv.data(), 4 * (size_t)nq) && rd(pur.data(), 4 * (size_t)nq) && rd(prad.data(), 4 * (size_t)nq) && rd(pmin.data(), 4 * (size_t)nq) &&
+                    rd(pmax.data(), 4 * (size_t)nq) && rd(pang.data(), 4 * (size_t)nq) && rd(pobs.data(), (size_t)nq) && rd(qd.data(), 32 * (size_t)nq);
+    std::fclose(fi);
+    if (!ok) return 3;
+    std::vector<cv::KeyPoint> keys(n);
+    for (int i = 0; i < n; i++) {
+        keys[i].pt.x = kx[i];
+        keys[i].pt.y = ky[i];
+        keys[i].octave = oct[i];
+        keys[i].angle = kang[i];
+    }
+    cv::Mat D(n, 32, CV_8UC1, desc.data(), (size_t)32);
+    orbfe::ProjectionSearch ps;
+    if (ps.build(keys, D, kur, f[0], f[1], f[2], f[3]) != 0) { std::fprintf(stderr, "track: %s\n", orbfe_last_error()); return 5; }
+    std::vector<orbfe::TrackedPoint> pts(nq);
+    for (int i = 0; i < nq; i++)
+        pts[i] = {pu[i], pv[i], pur[i], prad[i], pmin[i], pmax[i], pang[i], qd.data() + (size_t)i * 32, pobs[i] != 0};
+    std::vector<int> assigned;
+    int nmatches = 0;
+    if (ps.searchLastFrame(pts, kang, checkOri != 0, occ, assigned, &nmatches) != 0) {
+        std::fprintf(stderr, "track: %s\n", orbfe_last_error());
+        return 6;
+    }
+    FILE *fo = std::fopen(argv[3], "wb");
+    if (!fo) return 4;
+    const int rq = (int)ps.requeried();
+    std::fwrite(&nmatches, 4, 1, fo);
+    std::fwrite(&rq, 4, 1, fo);
+    std::fwrite(assigned.data(), 4, n, fo);
+    std::fwrite(occ.data(), 1, n, fo);
+    std::fclose(fo);
+    std::printf("adapter track ok: %d points, %d matches, %d searched again\n", nq, nmatches, rq);
+    return 0;
+}
+
 static int bowmatch_main(char **argv) {
     FILE *fi = std::fopen(argv[2], "rb");
     if (!fi) return 3;
@@ -167,6 +219,7 @@ static int bowmatch_main(char **argv) {
 
 int main(int argc, char **argv) {
     if (argc >= 4 && std::strcmp(argv[1], "bowmatch") == 0) return bowmatch_main(argv);
+    if (argc >= 4 && std::strcmp(argv[1], "track") == 0) return track_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "project") == 0) return project_main(argv);
     if (argc >= 7 && std::strcmp(argv[1], "bow") == 0) return bow_main(argv);
     if (argc >= 10 && std::strcmp(argv[1], "stereo") == 0) return stereo_main(argv);

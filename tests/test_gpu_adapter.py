@@ -216,3 +216,89 @@ def test_cpp_bow_matcher_matches_oracle(tmp_path, max_dist, check_ori):
         n_ref = before
     assert np.array_equal(match12, ref) and nmatches == n_ref
     assert n_ref > 300 and (not check_ori or n_ref < before)        # the histogram really removed something
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_cpp_track_last_frame_replays_the_reference_loop(tmp_path, check_ori):
+    """orbfe::ProjectionSearch::searchLastFrame == SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+    (src/ORBmatcher.cc:1328-1470) from the window search on, replayed sequentially on the oracle: forward / backward / normal
+    level ranges, the right-coordinate gate, unobserved (temporal) points whose keypoint can be overwritten, the histogram."""
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    assert exe.exists()
+    W, H = 1241, 376
+    img = synth.textured_image(W, H, synth.BASE_SEED + 654)
+    k, d = O.OracleExtractor(2000, 1.2, 8, 20, 7).extract(img)
+    n = len(k)
+    rng = np.random.default_rng(23)
+    kx, ky, koct, kang = k["x"].copy(), k["y"].copy(), k["octave"].astype(np.int32), k["angle"].copy()
+    kur = np.where(rng.uniform(size=n) < 0.5, kx - rng.uniform(1, 60, n), -1).astype(np.float32)
+    w_inv, h_inv = np.float32(64) / np.float32(W), np.float32(48) / np.float32(H)
+    sf = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * np.float32(1.2)
+    nq = 2200
+    src = rng.integers(0, n, nq)
+    pu = (kx[src] + rng.uniform(-4, 4, nq)).astype(np.float32)
+    pv = (ky[src] + rng.uniform(-4, 4, nq)).astype(np.float32)
+    pur = np.where(kur[src] > 0, kur[src] + rng.uniform(-3, 3, nq), pu - 25).astype(np.float32)
+    last_oct = np.clip(koct[src] + rng.integers(-1, 2, nq), 0, 7).astype(np.int32)
+    prad = (np.float32(15.0) * sf[last_oct]).astype(np.float32)             # th = 15 (stereo) as Tracking uses it
+    mode = rng.integers(0, 3, nq)                                           # forward / backward / neither (a call has one mode;
+    pmin = np.where(mode == 0, last_oct, np.where(mode == 1, 0, last_oct - 1)).astype(np.int32)   # mixing them covers all three)
+    pmax = np.where(mode == 0, -1, np.where(mode == 1, last_oct, last_oct + 1)).astype(np.int32)
+    # the scene rolled by ~12 degrees between the frames; some points have unrelated angles
+    pang = np.mod(np.where(rng.uniform(size=nq) < 0.85, kang[src] + 12 + rng.normal(0, 2, nq), rng.uniform(0, 360, nq)),
+                  360).astype(np.float32)
+    pobs = (rng.uniform(size=nq) < 0.7).astype(np.uint8)
+    qd = d[src].copy()
+    for i in range(nq):
+        for b in rng.integers(0, 256, 10):
+            qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    occ = (rng.uniform(size=n) < 0.1).astype(np.uint8)
+    case, out = tmp_path / "case.bin", tmp_path / "out.bin"
+    with open(case, "wb") as fh:
+        fh.write(np.array([n, nq, int(check_ori)], np.int32).tobytes())
+        fh.write(np.array([0.0, 0.0, w_inv, h_inv], np.float32).tobytes())
+        for a in (kx, ky, koct, kur, kang, d, occ, pu, pv, pur, prad, pmin, pmax, pang, pobs, qd):
+            fh.write(np.ascontiguousarray(a).tobytes())
+    r = subprocess.run([str(exe), "track", str(case), str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    nmatches, requeried = np.frombuffer(buf, np.int32, 2)
+    assigned = np.frombuffer(buf, np.int32, n, 8)
+    occ_out = np.frombuffer(buf, np.uint8, n, 8 + 4 * n)
+    # the reference's loop on the oracle
+    og = O.OracleGrid(kx, ky, koct, d, kur, 0.0, 0.0, float(w_inv), float(h_inv))
+    blocked = occ.copy()
+    want = np.full(n, -1, np.int32)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    overwritten = 0
+    for i in range(nq):
+        res = og.search(float(pu[i]), float(pv[i]), float(prad[i]), int(pmin[i]), int(pmax[i]), float(pur[i]), float(prad[i]), qd[i], blocked)
+        if res[5] == 0 or res[0] > 100:
+            continue
+        b = int(res[1])
+        overwritten += want[b] >= 0
+        want[b] = i
+        nm += 1
+        if pobs[i]:
+            blocked[b] = 1
+        if check_ori:
+            rot = np.float32(pang[i]) - np.float32(kang[b])
+            if rot < 0:
+                rot = np.float32(rot + np.float32(360))
+            v = float(np.float32(rot * np.float32(1.0 / 30)))
+            bn = int(np.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)        # C round(): half away from zero
+            hist[0 if bn == 30 else bn].append(b)
+    if check_ori:
+        keep = set(O.three_maxima([len(h) for h in hist]))
+        for bn in range(30):
+            if bn not in keep:
+                for b in hist[bn]:
+                    want[b] = -1
+                    blocked[b] = 0
+                    nm -= 1
+    assert np.array_equal(assigned, want) and nmatches == nm
+    assert np.array_equal(occ_out, blocked)
+    assert nm > 800 and requeried > 10 and overwritten > 0
