@@ -78,7 +78,22 @@ __device__ __forceinline__ u16x2 pksubsat(u16x2 a, u16x2 b) { return __builtin_e
 __device__ __forceinline__ u16x2 pair_even(uint32_t w) { return as_pk(w & 0x00FF00FFu); }
 __device__ __forceinline__ u16x2 pair_odd(uint32_t w) { return as_pk(__builtin_amdgcn_perm(0u, w, 0x0c030c01u)); }
 
-// arc score of two pixels at once: v = centres, r[k] = ring values, all in 16-bit lanes holding 0..255
+// gfx950 has three-input packed min / max (v_pk_minimum3_f16 / v_pk_maximum3_f16) at the rate of the two-input packed
+// ops (measured, profiles/r1_valu_rates_ubench.txt).  Pixel pairs carry a bias of 0x4000 in each 16-bit lane (fast_row_pairs),
+// which makes them normal half-precision numbers 2.0 + p/512 ordered like p, so the float min / max select exactly what
+// the integer ones would, whatever the denormal mode; differences of two biased values are the unbiased differences.
+__device__ __forceinline__ u16x2 pkmax3(u16x2 a, u16x2 b, u16x2 c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)), "v"(__builtin_bit_cast(uint32_t, c)));
+    return __builtin_bit_cast(u16x2, d);
+}
+__device__ __forceinline__ u16x2 pkmin3(u16x2 a, u16x2 b, u16x2 c) {
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)), "v"(__builtin_bit_cast(uint32_t, c)));
+    return __builtin_bit_cast(u16x2, d);
+}
+
+// arc score of two pixels at once: v = centres, r[k] = ring values, all in 16-bit lanes holding 0x4000 + (0..255)
 __device__ __forceinline__ u16x2 fast_arc_score_pk(u16x2 v, const u16x2 (&r)[16]) {
     u16x2 x2[8], n2[8], x4[8], n4[8];
 #pragma unroll
@@ -91,14 +106,16 @@ __device__ __forceinline__ u16x2 fast_arc_score_pk(u16x2 v, const u16x2 (&r)[16]
         x4[i] = pkmax(x2[i], x2[(i + 1) & 7]);
         n4[i] = pkmin(n2[i], n2[(i + 1) & 7]);
     }
-    u16x2 minOfMax = as_pk(0x00FF00FFu), maxOfMin = as_pk(0u);
+    // windows k = 2i and k+1 share ring[k+1..k+8] = M8[j = k+1]:  min(maxW_k, maxW_k+1) = max(M8, min(r[k], r[k+9]))
+    u16x2 wx[8], wn[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {      // windows k = 2i and k+1 share ring[k+1..k+8] = M8[j = k+1]
+    for (int i = 0; i < 8; i++) {
         const int k = 2 * i;
-        const u16x2 x8 = pkmax(x4[i], x4[(i + 2) & 7]), n8 = pkmin(n4[i], n4[(i + 2) & 7]);
-        minOfMax = pkmin(minOfMax, pkmax(x8, pkmin(r[k], r[(k + 9) & 15])));
-        maxOfMin = pkmax(maxOfMin, pkmin(n8, pkmax(r[k], r[(k + 9) & 15])));
+        wx[i] = pkmax3(x4[i], x4[(i + 2) & 7], pkmin(r[k], r[(k + 9) & 15]));
+        wn[i] = pkmin3(n4[i], n4[(i + 2) & 7], pkmax(r[k], r[(k + 9) & 15]));
     }
+    const u16x2 minOfMax = pkmin(pkmin3(pkmin3(wx[0], wx[1], wx[2]), pkmin3(wx[3], wx[4], wx[5]), wx[6]), wx[7]);
+    const u16x2 maxOfMin = pkmax(pkmax3(pkmax3(wn[0], wn[1], wn[2]), pkmax3(wn[3], wn[4], wn[5]), wn[6]), wn[7]);
     return pkmax(pksubsat(v, minOfMax), pksubsat(maxOfMin, v));   // max(S, 0)
 }
 
@@ -115,10 +132,11 @@ struct FastRowS {      // one row of scores in pair form, with what the 3x3 test
     u16x2 me, mo;      // max of left, centre, right in this row (what the rows above/below see)
 };
 
-// one image row in pair form: q[o + 3] = pixels (x0 + o, x0 + o + 2) of the lane's dword, o = -3..4
+// one image row in pair form: q[o + 3] = pixels (x0 + o, x0 + o + 2) of the lane's dword, o = -3..4, each 16-bit lane
+// biased by 0x4000 (see pkmax3)
 __device__ __forceinline__ void fast_row_pairs(uint32_t raw, uint32_t (&q)[8]) {
-    const uint32_t E = raw & 0x00FF00FFu;                                   // (p0, p2)
-    const uint32_t O = __builtin_amdgcn_perm(0u, raw, 0x0c030c01u);         // (p1, p3)
+    const uint32_t E = (raw & 0x00FF00FFu) | 0x40004000u;                   // (p0, p2)
+    const uint32_t O = __builtin_amdgcn_perm(0x40404040u, raw, 0x04030401u);   // (p1, p3)
     const uint32_t EL = dpp_from_left(E), OL = dpp_from_left(O);            // (p-4, p-2), (p-3, p-1)
     const uint32_t ER = dpp_from_right(E), OR = dpp_from_right(O);          // (p4, p6),  (p5, p7)
     q[0] = OL;

@@ -65,6 +65,10 @@
 #define A_PKMAXI(r) "v_pk_max_i16 " r ", " r ", %8"
 #define A_MAX3F(r) "v_max3_f32 " r ", " r ", %8, %9"
 #define A_MAX3F16(r) "v_max3_f16 " r ", " r ", %8, %9"
+#define A_PKMAX3F(r) "v_pk_maximum3_f16 " r ", " r ", %8, %9"
+#define A_PKMIN3F(r) "v_pk_minimum3_f16 " r ", " r ", %8, %9"
+#define A_MAX3U16(r) "v_max3_u16 " r ", " r ", %8, %9"
+#define A_MAXIMUM3F32(r) "v_maximum3_f32 " r ", " r ", %8, %9"
 #define A_PKMULF(r) "v_pk_mul_f32 " r ", " r ", %8"
 
 DEFKERNEL(k_xor, A_XOR)
@@ -94,6 +98,10 @@ DEFKERNEL(k_cvtub, A_CVTUB)
 DEFKERNEL(k_pkmaxi, A_PKMAXI)
 DEFKERNEL(k_max3f, A_MAX3F)
 DEFKERNEL(k_max3f16, A_MAX3F16)
+DEFKERNEL(k_pkmax3f, A_PKMAX3F)
+DEFKERNEL(k_pkmin3f, A_PKMIN3F)
+DEFKERNEL(k_max3u16, A_MAX3U16)
+DEFKERNEL(k_maximum3f32, A_MAXIMUM3F32)
 DEFKERNEL(k_bcnt, A_BCNT)
 DEFKERNEL(k_pkmax, A_PKMAX)
 DEFKERNEL(k_max3, A_MAX3)
@@ -125,7 +133,8 @@ int main() {
         {"v_max_i32", k_maxi}, {"v_min_u16", k_minu16}, {"v_sad_u8", k_sad}, {"v_pk_mad_u16", k_pkmad},
         {"v_dot2_u32_u16", k_dot2}, {"v_sub_u32", k_sub}, {"v_lshlrev_b32", k_lshl}, {"v_bfe_u32", k_bfe},
         {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_cvt_f32_ubyte0", k_cvtub}, {"v_pk_max_i16", k_pkmaxi},
-        {"v_max3_f32", k_max3f}, {"v_max3_f16", k_max3f16}};
+        {"v_max3_f32", k_max3f}, {"v_max3_f16", k_max3f16}, {"v_pk_maximum3_f16", k_pkmax3f},
+        {"v_pk_minimum3_f16", k_pkmin3f}, {"v_max3_u16", k_max3u16}, {"v_maximum3_f32", k_maximum3f32}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
