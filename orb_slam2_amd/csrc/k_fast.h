@@ -82,15 +82,16 @@ __device__ __forceinline__ u16x2 pair_odd(uint32_t w) { return as_pk(__builtin_a
 // ops (measured, profiles/r1_valu_rates_ubench.txt).  Pixel pairs carry a bias of 0x4000 in each 16-bit lane (fast_row_pairs),
 // which makes them normal half-precision numbers 2.0 + p/512 ordered like p, so the float min / max select exactly what
 // the integer ones would, whatever the denormal mode; differences of two biased values are the unbiased differences.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 pkmax3(u16x2 a, u16x2 b, u16x2 c) {
-    uint32_t d;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)), "v"(__builtin_bit_cast(uint32_t, c)));
-    return __builtin_bit_cast(u16x2, d);
+    const f16x2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+                                                  __builtin_bit_cast(f16x2, c));
+    return __builtin_bit_cast(u16x2, m);
 }
 __device__ __forceinline__ u16x2 pkmin3(u16x2 a, u16x2 b, u16x2 c) {
-    uint32_t d;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)), "v"(__builtin_bit_cast(uint32_t, c)));
-    return __builtin_bit_cast(u16x2, d);
+    const f16x2 m = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+                                                  __builtin_bit_cast(f16x2, c));
+    return __builtin_bit_cast(u16x2, m);
 }
 
 // arc score of two pixels at once: v = centres, r[k] = ring values, all in 16-bit lanes holding 0x4000 + (0..255)
@@ -120,10 +121,10 @@ __device__ __forceinline__ u16x2 fast_arc_score_pk(u16x2 v, const u16x2 (&r)[16]
 }
 
 __device__ __forceinline__ uint32_t dpp_from_left(uint32_t v) {    // lane i <- lane i-1 (0 into lane 0)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t dpp_from_right(uint32_t v) {   // lane i <- lane i+1 (0 into lane 63)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
 struct FastRowS {      // one row of scores in pair form, with what the 3x3 test needs from it
