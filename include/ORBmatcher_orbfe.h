@@ -11,12 +11,18 @@
 //     orbfe::BowMatcher below
 //   * Frame::GetFeaturesInArea (src/Frame.cc:327-380) + the candidate loop of SearchByProjection(Frame&, vpMapPoints, th)
 //     (src/ORBmatcher.cc:45-129): orbfe::ProjectionSearch below
+//   * the other guided searches from their window search on -- SearchByProjection(KeyFrame*, Scw, ...) (:290-403),
+//     SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1472-1599), both Fuse overloads (:825-975, :977-1100),
+//     SearchBySim3 (:1102-1326), SearchForInitialization (:405-520): further members of orbfe::ProjectionSearch;
+//     SearchForTriangulation (:657-823): orbfe::TriangulationMatcher
 // INTEGRATION.md shows the two-line patches.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <climits>
 #include <cmath>
 #include <map>
+#include <utility>
 #include <vector>
 
 #include "orbfe.h"
@@ -315,9 +321,225 @@ public:
         *nmatches = n;
         return ORBFE_OK;
     }
+    // ---- the remaining window searches.  One WindowPoint = one MapPoint (or F1 keypoint) that reached the window search of
+    // its routine, with the values the reference has computed on the host by then.
+    struct WindowPoint {
+        float u, v;                   // projection (or vbPrevMatched[i1])
+        float ur;                     // u - bf * invz, used by the Fuse gate only
+        float radius;                 // th * mvScaleFactors[nPredictedLevel] (or windowSize)
+        int level;                    // nPredictedLevel (or level1)
+        float angle;                  // the keypoint angle the rotation histogram uses for this point
+        const unsigned char *desc;    // pMP->GetDescriptor() (or F1.mDescriptors.row(i1))
+        int index;                    // SearchBySim3 / SearchForInitialization: the keypoint of the other frame it belongs to
+    };
+    // SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, th) from :359 on; build() was called with pKF's
+    // members.  matched[idx] != 0 where vpMatched[idx] is set (:375), updated as :396 does; matchIdx[i] = keypoint or -1.
+    int searchSim3Projection(const std::vector<WindowPoint> &pts, std::vector<unsigned char> &matched, std::vector<int> &matchIdx,
+                             int *nmatches) {
+        return bestWithReplay(pts, -1, 0, 50 /* TH_LOW, :394 */, true, nullptr, 0, matched, matchIdx, nmatches);
+    }
+    // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) from :1525 on; build() was called
+    // with CurrentFrame's members, curAngles = CurrentFrame.mvKeysUn[*].angle, pts[i].angle = pKF->mvKeysUn[i].angle.
+    // occupied[i2] != 0 where CurrentFrame.mvpMapPoints[i2] is set (:1541); assigned[i2] = index into pts or -1.
+    int searchRelocalization(const std::vector<WindowPoint> &pts, const std::vector<float> &curAngles, int ORBdist,
+                             bool checkOrientation, std::vector<unsigned char> &occupied, std::vector<int> &assigned, int *nmatches) {
+        assigned.assign(n_, -1);
+        *nmatches = 0;
+        if ((int)curAngles.size() != n_) return ORBFE_ERR_ARG;
+        std::vector<int> matchIdx;
+        int n = 0;
+        const int rc = bestWithReplay(pts, -1, +1, ORBdist, true, nullptr, 0, occupied, matchIdx, &n);
+        if (rc != ORBFE_OK) return rc;
+        const int HISTO_LENGTH = 30;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        const float factor = 1.0f / HISTO_LENGTH;
+        for (size_t i = 0; i < pts.size(); i++) {
+            if (matchIdx[i] < 0) continue;
+            assigned[matchIdx[i]] = (int)i;                                    // :1557
+            if (checkOrientation) {                                            // :1560-1570
+                float rot = pts[i].angle - curAngles[matchIdx[i]];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(matchIdx[i]);
+            }
+        }
+        if (checkOrientation) {                                                // :1577-1596
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    assigned[rotHist[i][j]] = -1;
+                    occupied[rotHist[i][j]] = 0;
+                    n--;
+                }
+            }
+        }
+        *nmatches = n;
+        return ORBFE_OK;
+    }
+    // The selection part of Fuse(KeyFrame *pKF, vpMapPoints, th) (:889-952; pass pKF->mvInvLevelSigma2) and of
+    // Fuse(KeyFrame *pKF, Scw, vpPoints, th, vpReplacePoint) (:1048-1082; pass an empty vector: that overload has no
+    // reprojection gate).  bestIdx[i] = the keypoint MapPoint i is fused into, or -1; what :954-970 / :1084-1095 then do to
+    // the map stays with the caller.  No candidate is skipped because of earlier fusions, so one launch serves all points.
+    int fuseSelect(const std::vector<WindowPoint> &pts, const std::vector<float> &invLevelSigma2, std::vector<int> &bestIdx,
+                   int *nFused) {
+        std::vector<unsigned char> none;
+        return bestWithReplay(pts, -1, 0, 50 /* TH_LOW */, false, invLevelSigma2.empty() ? nullptr : invLevelSigma2.data(),
+                              (int)invLevelSigma2.size(), none, bestIdx, nFused);
+    }
+    // SearchBySim3 (:1102-1326) from the window searches on.  kf1 / kf2 were built with pKF1's / pKF2's members; pts1 are the
+    // MapPoints of KF1 projected into KF2 (index = i1), pts2 those of KF2 projected into KF1 (index = i2).
+    // match12[i1] = idx2 where both directions agree (:1307-1323), else -1.
+    static int SearchBySim3(ProjectionSearch &kf1, ProjectionSearch &kf2, const std::vector<WindowPoint> &pts1,
+                            const std::vector<WindowPoint> &pts2, std::vector<int> &match12, int *nFound) {
+        std::vector<unsigned char> none;
+        std::vector<int> b1, b2, vnMatch1(kf1.n_, -1), vnMatch2(kf2.n_, -1);
+        int dummy = 0;
+        int rc = kf2.bestWithReplay(pts1, -1, 0, 100 /* TH_HIGH, :1221 */, false, nullptr, 0, none, b1, &dummy);
+        if (rc == ORBFE_OK) rc = kf1.bestWithReplay(pts2, -1, 0, 100, false, nullptr, 0, none, b2, &dummy);
+        if (rc != ORBFE_OK) return rc;
+        for (size_t a = 0; a < pts1.size(); a++)
+            if (b1[a] >= 0) vnMatch1[pts1[a].index] = b1[a];
+        for (size_t a = 0; a < pts2.size(); a++)
+            if (b2[a] >= 0) vnMatch2[pts2[a].index] = b2[a];
+        match12.assign(kf1.n_, -1);
+        *nFound = 0;
+        for (int i1 = 0; i1 < kf1.n_; i1++) {
+            const int idx2 = vnMatch1[i1];
+            if (idx2 >= 0 && vnMatch2[idx2] == i1) {
+                match12[i1] = idx2;
+                (*nFound)++;
+            }
+        }
+        return ORBFE_OK;
+    }
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:405-520); build() was called with F2's members,
+    // angles2 = F2.mvKeysUn[*].angle, pts2xy = F2.mvKeysUn[*].pt.  pts holds the level-0 keypoints of F1 in index order
+    // (index = i1, u/v = vbPrevMatched[i1], radius = windowSize, level = 0).  All windows are searched in one launch with
+    // vMatchedDistance = INT_MAX; the loop is then replayed in order, and a keypoint whose best or second candidate has
+    // meanwhile been matched at a distance <= its own (:444) is searched again against the current vMatchedDistance.
+    int searchForInitialization(const std::vector<WindowPoint> &pts, int n1, const std::vector<float> &angles2, float nnRatio,
+                                bool checkOrientation, std::vector<int> &vnMatches12, int *nmatches) {
+        vnMatches12.assign(n1, -1);
+        *nmatches = 0;
+        const int nq = (int)pts.size();
+        if (nq == 0 || n_ == 0) return ORBFE_OK;
+        if ((int)angles2.size() != n_) return ORBFE_ERR_ARG;
+        std::vector<orbfe_area_query> q(nq);
+        std::vector<unsigned char> qd((size_t)nq * 32);
+        for (int i = 0; i < nq; i++) {
+            q[i].x = pts[i].u; q[i].y = pts[i].v; q[i].r = pts[i].radius;
+            q[i].min_level = pts[i].level; q[i].max_level = pts[i].level;   // :425
+            q[i].proj_xr = 0; q[i].er_max = -1.0f; q[i].pad = 0;
+            for (int b = 0; b < 32; b++) qd[(size_t)i * 32 + b] = pts[i].desc[b];
+        }
+        std::vector<orbfe_area_result> res(nq);
+        orbfe_area_options opt = orbfe_area_options();
+        int rc = orbfe_search_area_ex(m_, g_, q.data(), qd.data(), nq, &opt, res.data());
+        if (rc != ORBFE_OK) return rc;
+        const int HISTO_LENGTH = 30, TH_LOW = 50;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        const float factor = 1.0f / HISTO_LENGTH;
+        std::vector<int32_t> vMatchedDistance(n_, INT_MAX);
+        std::vector<int> vnMatches21(n_, -1);
+        int n = 0;
+        for (int i = 0; i < nq; i++) {
+            orbfe_area_result r = res[i];
+            if ((r.best_idx >= 0 && vMatchedDistance[r.best_idx] <= r.best_dist) ||
+                (r.best_idx2 >= 0 && vMatchedDistance[r.best_idx2] <= r.best_dist2)) {
+                opt.dist_limit = vMatchedDistance.data();
+                rc = orbfe_search_area_ex(m_, g_, &q[i], &qd[(size_t)i * 32], 1, &opt, &r);
+                if (rc != ORBFE_OK) return rc;
+                requeried_++;
+            }
+            const int bestDist = r.best_idx < 0 ? INT_MAX : r.best_dist;       // the loop starts from INT_MAX (:432-433)
+            const int bestDist2 = r.best_idx2 < 0 ? INT_MAX : r.best_dist2;
+            if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * nnRatio) { // :459-461
+                const int i1 = pts[i].index, bestIdx2 = r.best_idx;
+                if (vnMatches21[bestIdx2] >= 0) {
+                    vnMatches12[vnMatches21[bestIdx2]] = -1;
+                    n--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                n++;
+                if (checkOrientation) {
+                    float rot = pts[i].angle - angles2[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+        if (checkOrientation) {                                                // :489-512
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    const int idx1 = rotHist[i][j];
+                    if (vnMatches12[idx1] >= 0) {
+                        vnMatches12[idx1] = -1;
+                        n--;
+                    }
+                }
+            }
+        }
+        *nmatches = n;   // the caller then updates vbPrevMatched from vnMatches12 (:514-517)
+        return ORBFE_OK;
+    }
     long requeried() const { return requeried_; }
 
 private:
+    // best candidate per point in [level + dLo, level + dHi] with the reference's strict '<' scan, accepted up to maxDist;
+    // blockAccepted: an accepted keypoint is skipped by later points (vpMatched / mvpMapPoints written inside the loop).
+    int bestWithReplay(const std::vector<WindowPoint> &pts, int dLo, int dHi, int maxDist, bool blockAccepted,
+                       const float *invLevelSigma2, int nlevels, std::vector<unsigned char> &occupied, std::vector<int> &matchIdx,
+                       int *nmatches) {
+        const int nq = (int)pts.size();
+        matchIdx.assign(nq, -1);
+        *nmatches = 0;
+        if (nq == 0 || n_ == 0) return ORBFE_OK;
+        if (blockAccepted && (int)occupied.size() != n_) return ORBFE_ERR_ARG;
+        std::vector<orbfe_area_query> q(nq);
+        std::vector<unsigned char> qd((size_t)nq * 32);
+        for (int i = 0; i < nq; i++) {
+            q[i].x = pts[i].u; q[i].y = pts[i].v; q[i].r = pts[i].radius;
+            q[i].min_level = pts[i].level + dLo; q[i].max_level = pts[i].level + dHi;
+            q[i].proj_xr = pts[i].ur; q[i].er_max = -1.0f; q[i].pad = 0;
+            for (int b = 0; b < 32; b++) qd[(size_t)i * 32 + b] = pts[i].desc[b];
+        }
+        orbfe_area_options opt = orbfe_area_options();
+        opt.blocked = blockAccepted ? occupied.data() : nullptr;
+        opt.inv_level_sigma2 = invLevelSigma2;
+        opt.nlevels = nlevels;
+        opt.chi2_mono = 5.99;
+        opt.chi2_stereo = 7.8;
+        std::vector<orbfe_area_result> res(nq);
+        int rc = orbfe_search_area_ex(m_, g_, q.data(), qd.data(), nq, &opt, res.data());
+        if (rc != ORBFE_OK) return rc;
+        std::vector<unsigned char> taken(blockAccepted ? n_ : 0, 0);
+        for (int i = 0; i < nq; i++) {
+            orbfe_area_result r = res[i];
+            if (blockAccepted && r.best_idx >= 0 && taken[r.best_idx]) {
+                rc = orbfe_search_area_ex(m_, g_, &q[i], &qd[(size_t)i * 32], 1, &opt, &r);
+                if (rc != ORBFE_OK) return rc;
+                requeried_++;
+            }
+            if (r.best_idx < 0 || r.best_dist > maxDist) continue;
+            matchIdx[i] = r.best_idx;
+            (*nmatches)++;
+            if (blockAccepted) {
+                occupied[r.best_idx] = 1;
+                taken[r.best_idx] = 1;
+            }
+        }
+        return ORBFE_OK;
+    }
     int dev_;
     orbfe_matcher *m_;
     orbfe_frame_grid *g_;
@@ -401,6 +623,97 @@ public:
     }
     static void ComputeThreeMaxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
         three_maxima(histo, L, ind1, ind2, ind3);
+    }
+
+private:
+    orbfe_matcher *m_;
+};
+
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823).  fv1 / fv2: pKF1->mFeatVec / pKF2->mFeatVec; hasMp1 / hasMp2:
+// GetMapPoint(idx) != NULL; uRight1 / uRight2: mvuRight; keys1 / keys2: mvKeysUn; F12 as the reference's 3x3 CV_32F matrix in
+// row-major order; ex, ey: the epipole the reference computes at :664-670; scaleFactors2 / levelSigma2: pKF2's tables.
+class TriangulationMatcher {
+public:
+    typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+    explicit TriangulationMatcher(int device = 0) : m_(nullptr) { orbfe_matcher_create(device, &m_); }
+    ~TriangulationMatcher() { orbfe_matcher_destroy(m_); }
+    int SearchForTriangulation(const FeatureVector &fv1, const cv::Mat &desc1, const std::vector<cv::KeyPoint> &keys1,
+                               const std::vector<unsigned char> &hasMp1, const std::vector<float> &uRight1, const FeatureVector &fv2,
+                               const cv::Mat &desc2, const std::vector<cv::KeyPoint> &keys2, const std::vector<unsigned char> &hasMp2,
+                               const std::vector<float> &uRight2, const float F12[9], float ex, float ey,
+                               const std::vector<float> &scaleFactors2, const std::vector<float> &levelSigma2, bool bOnlyStereo,
+                               bool checkOrientation, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, int *nmatches) {
+        const int n1 = (int)keys1.size(), n2 = (int)keys2.size();
+        vMatchedPairs.clear();
+        *nmatches = 0;
+        std::vector<int32_t> off1(1, 0), off2(1, 0), idx1, idx2;                // the merge walk of :691-789
+        FeatureVector::const_iterator it1 = fv1.begin(), it2 = fv2.begin();
+        while (it1 != fv1.end() && it2 != fv2.end()) {
+            if (it1->first == it2->first) {
+                idx1.insert(idx1.end(), it1->second.begin(), it1->second.end());
+                idx2.insert(idx2.end(), it2->second.begin(), it2->second.end());
+                off1.push_back((int32_t)idx1.size());
+                off2.push_back((int32_t)idx2.size());
+                ++it1;
+                ++it2;
+            } else if (it1->first < it2->first) {
+                it1 = fv1.lower_bound(it2->first);
+            } else {
+                it2 = fv2.lower_bound(it1->first);
+            }
+        }
+        if (off1.size() == 1 || n1 == 0 || n2 == 0) return ORBFE_OK;
+        std::vector<unsigned char> d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+        std::vector<float> xy1((size_t)n1 * 2), xy2((size_t)n2 * 2);
+        std::vector<int32_t> oct2(n2);
+        for (int i = 0; i < n1; i++) {
+            for (int b = 0; b < 32; b++) d1[(size_t)i * 32 + b] = desc1.ptr(i)[b];
+            xy1[2 * i] = keys1[i].pt.x; xy1[2 * i + 1] = keys1[i].pt.y;
+        }
+        for (int i = 0; i < n2; i++) {
+            for (int b = 0; b < 32; b++) d2[(size_t)i * 32 + b] = desc2.ptr(i)[b];
+            xy2[2 * i] = keys2[i].pt.x; xy2[2 * i + 1] = keys2[i].pt.y;
+            oct2[i] = keys2[i].octave;
+        }
+        std::vector<int32_t> vMatches12(n1, -1);
+        const int rc = orbfe_search_for_triangulation(m_, d1.data(), hasMp1.data(), uRight1.data(), xy1.data(), n1, d2.data(),
+                                                      hasMp2.data(), uRight2.data(), xy2.data(), oct2.data(), n2, off1.data(),
+                                                      idx1.data(), off2.data(), idx2.data(), (int)off1.size() - 1, F12, ex, ey,
+                                                      scaleFactors2.data(), levelSigma2.data(), (int)scaleFactors2.size(),
+                                                      bOnlyStereo ? 1 : 0, vMatches12.data());
+        if (rc != ORBFE_OK) return rc;
+        const int HISTO_LENGTH = 30;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        const float factor = 1.0f / HISTO_LENGTH;
+        int n = 0;
+        // the histogram is filled in the order the reference's loop visits the side-1 features (node by node); the bins'
+        // contents are only counted and cleared, so index order gives the same result
+        for (int i = 0; i < n1; i++) {
+            if (vMatches12[i] < 0) continue;
+            n++;
+            if (!checkOrientation) continue;
+            float rot = keys1[i].angle - keys2[vMatches12[i]].angle;           // :764-774
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(i);
+        }
+        if (checkOrientation) {                                                // :791-810
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    vMatches12[rotHist[i][j]] = -1;
+                    n--;
+                }
+            }
+        }
+        vMatchedPairs.reserve(n);                                              // :812-820
+        for (int i = 0; i < n1; i++)
+            if (vMatches12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)vMatches12[i]));
+        *nmatches = n;
+        return ORBFE_OK;
     }
 
 private:

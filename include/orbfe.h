@@ -231,6 +231,27 @@ int orbfe_frame_grid_destroy(orbfe_frame_grid *g);
  * is made; associations made DURING the reference's loop are the caller's to replay).  Synchronous. */
 int orbfe_search_area(orbfe_matcher *m, orbfe_frame_grid *g, const orbfe_area_query *queries, const uint8_t *query_desc, int nq,
                       const uint8_t *blocked, orbfe_area_result *results);
+/* The same windowed search with the per-candidate tests of the other guided searches (KeyFrame::GetFeaturesInArea,
+ * src/KeyFrame.cc:569-608, is Frame::GetFeaturesInArea with min_level = max_level = -1 on the same 64 x 48 grid, so one grid
+ * type serves Frame and KeyFrame):
+ *   blocked           keypoints the loop skips: vpMatched[idx] (src/ORBmatcher.cc:375), CurrentFrame.mvpMapPoints[i2] (:1541)
+ *   dist_limit        SearchForInitialization (:444): skip idx when dist_limit[idx] <= dist (vMatchedDistance), n ints or NULL
+ *   inv_level_sigma2  Fuse(KeyFrame*, vpMapPoints, th) (:914-938): with u = query x, v = query y, ur = proj_xr, skip idx when
+ *                     (ex^2 + ey^2 [+ er^2 if mvuRight[idx] >= 0]) * inv_level_sigma2[octave] > chi2_mono [chi2_stereo]
+ *                     (5.99 / 7.8); nlevels floats or NULL = no gate.  float products and sums individually rounded.
+ * The level test of those loops (kpLevel in [nPredictedLevel-1, nPredictedLevel], :380, :911, :1067, :1207, :1287) is the
+ * query's min_level / max_level; set er_max < 0 where the loop has no right-coordinate test.  Results as orbfe_search_area
+ * (loops that start from INT_MAX instead of 256, :432, :1060, :1199, see 256 where nothing was compared: best_idx = -1). */
+typedef struct orbfe_area_options {
+    const uint8_t *blocked;
+    const int32_t *dist_limit;
+    const float *inv_level_sigma2;
+    int32_t nlevels;
+    int32_t pad;
+    double chi2_mono, chi2_stereo;
+} orbfe_area_options;
+int orbfe_search_area_ex(orbfe_matcher *m, orbfe_frame_grid *g, const orbfe_area_query *queries, const uint8_t *query_desc, int nq,
+                         const orbfe_area_options *opt, orbfe_area_result *results);
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:159-288) and SearchByBoW(KeyFrame*, KeyFrame*, ...)
  * (:522-655) without the rotation histogram: for every vocabulary node present in both feature vectors (the caller's
  * merge walk, :180-264, gives node_off / node_idx for both sides in FeatureVector order), each side-1 feature with
@@ -244,6 +265,20 @@ int orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *desc1, const uint8_t *v
                         const uint8_t *blocked2, int n2, const int32_t *node_off1, const int32_t *node_idx1,
                         const int32_t *node_off2, const int32_t *node_idx2, int n_nodes, int max_dist, float nn_ratio,
                         int32_t *match1);
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823) without the rotation histogram: shared nodes as in
+ * orbfe_search_by_bow; has_mp1 / has_mp2: GetMapPoint(idx) != NULL (:699-703, :722-726); uright1 / uright2: mvuRight (a value
+ * >= 0 makes the keypoint a stereo one, :705, :728); xy1 / xy2: mvKeysUn[*].pt as (x, y) pairs; oct2: mvKeysUn[*].octave of
+ * side 2; F12: the fundamental matrix, row-major 3 x 3 floats; ex, ey: the epipole of :664-670; scale_factors /
+ * level_sigma2: pKF2->mvScaleFactors / mvLevelSigma2 (nlevels <= 16 entries).  A side-1 feature takes the side-2 feature of its
+ * node with the least distance <= TH_LOW among those passing the epipole test (:743-749) and CheckDistEpipolarLine
+ * (:140-157); of equal distances the last in list order wins (`dist > bestDist` at :738).  match1[idx1] = idx2 or -1.
+ * Host pointers, synchronous.  include/ORBmatcher_orbfe.h adds the histogram and vMatchedPairs. */
+int orbfe_search_for_triangulation(orbfe_matcher *m, const uint8_t *desc1, const uint8_t *has_mp1, const float *uright1,
+                                   const float *xy1, int n1, const uint8_t *desc2, const uint8_t *has_mp2, const float *uright2,
+                                   const float *xy2, const int32_t *oct2, int n2, const int32_t *node_off1,
+                                   const int32_t *node_idx1, const int32_t *node_off2, const int32_t *node_idx2, int n_nodes,
+                                   const float *F12, float ex, float ey, const float *scale_factors, const float *level_sigma2,
+                                   int nlevels, int only_stereo, int32_t *match1);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

@@ -1093,6 +1093,315 @@ void orc_search_area(const orc_grid *g, const uint8_t *kdesc, const float *urigh
     res[6] = bestIdx2;
 }
 
+/* The candidate loops of the remaining guided searches, on the same grid (KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:569-608,
+ * is Frame::GetFeaturesInArea without a level test).  best only: these loops keep no second place. */
+static int window_best(const orc_grid *g, const uint8_t *kdesc, const uint8_t *blocked, float u, float v, float radius,
+                       int levelLo, int levelHi, bool levelsInWindow, const uint8_t *dMP, int *bestDistOut) {
+    std::vector<int32_t> vIndices(g->kx.size() + 1);
+    /* Frame version filters the levels inside GetFeaturesInArea (:1528); the KeyFrame loops filter after it (:380, :911, ...) */
+    const int n = levelsInWindow ? orc_features_in_area(g, u, v, radius, levelLo, levelHi, vIndices.data())
+                                 : orc_features_in_area(g, u, v, radius, -1, -1, vIndices.data());
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < n; k++) {
+        const int idx = vIndices[k];
+        if (blocked && blocked[idx]) continue;
+        if (!levelsInWindow) {
+            const int kpLevel = g->koct[idx];
+            if (kpLevel < levelLo || kpLevel > levelHi) continue;
+        }
+        const int dist = hamming(dMP, kdesc + (size_t)idx * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    *bestDistOut = bestDist;
+    return bestIdx;
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) from the window search on (src/ORBmatcher.cc:359-399):
+ * query i is a MapPoint that passed the projection tests (:317-355) with its u, v, radius = th * scale[nPredictedLevel];
+ * matched[idx] != 0 where vpMatched[idx] is set (updated here as :396 does); match_idx[i] = keypoint or -1. */
+int orc_search_by_projection_sim3(const orc_grid *g, const uint8_t *kdesc, int nq, const float *u, const float *v,
+                                  const float *radius, const int32_t *level, const uint8_t *qdesc, uint8_t *matched,
+                                  int32_t *match_idx) {
+    int nmatches = 0;
+    for (int i = 0; i < nq; i++) {
+        match_idx[i] = -1;
+        int bestDist;
+        const int bestIdx = window_best(g, kdesc, matched, u[i], v[i], radius[i], level[i] - 1, level[i], false,
+                                        qdesc + (size_t)i * 32, &bestDist);
+        if (bestDist <= 50) {            /* TH_LOW, :394 */
+            matched[bestIdx] = 1;        /* :396 */
+            match_idx[i] = bestIdx;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) from the window search on
+ * (:1525-1598): occupied[i2] != 0 where CurrentFrame.mvpMapPoints[i2] is set; assigned[i2] = query whose MapPoint the keypoint
+ * ends up with, or -1; qangle = pKF->mvKeysUn[i].angle, kangle = CurrentFrame.mvKeysUn[*].angle. */
+int orc_search_by_projection_reloc(const orc_grid *g, const uint8_t *kdesc, const float *kangle, int nq, const float *u,
+                                   const float *v, const float *radius, const int32_t *level, const float *qangle,
+                                   const uint8_t *qdesc, int orb_dist, int check_orientation, uint8_t *occupied,
+                                   int32_t *assigned) {
+    const int HISTO_LENGTH = 30;
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const int n = (int)g->kx.size();
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < nq; i++) {
+        int bestDist;
+        const int bestIdx2 = window_best(g, kdesc, occupied, u[i], v[i], radius[i], level[i] - 1, level[i] + 1, true,
+                                         qdesc + (size_t)i * 32, &bestDist);
+        if (bestIdx2 >= 0 && bestDist <= orb_dist) {   /* :1555 (bestIdx2 < 0 only with bestDist = 256 > any ORBdist in use) */
+            occupied[bestIdx2] = 1;                    /* :1557 */
+            assigned[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = qangle[i] - kangle[bestIdx2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[30], ind[3];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int32_t)rotHist[i].size();
+        orc_three_maxima(sizes, HISTO_LENGTH, ind);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind[0] && i != ind[1] && i != ind[2])
+                for (int j : rotHist[i]) {
+                    occupied[j] = 0;                   /* :1591 */
+                    assigned[j] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
+/* The selection part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (:889-952, use_chi2 != 0) and of
+ * Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:1048-1082, use_chi2 == 0): best_idx[i] = the keypoint the MapPoint is
+ * fused into (bestDist <= TH_LOW) or -1.  What happens to the map afterwards (:954-970, :1084-1095) is the caller's. */
+int orc_fuse_select(const orc_grid *g, const uint8_t *kdesc, const float *uright, const float *inv_level_sigma2, int use_chi2,
+                    int nq, const float *u, const float *v, const float *ur, const float *radius, const int32_t *level,
+                    const uint8_t *qdesc, int32_t *best_idx) {
+    int nFused = 0;
+    std::vector<int32_t> vIndices(g->kx.size() + 1);
+    for (int i = 0; i < nq; i++) {
+        best_idx[i] = -1;
+        const int n = orc_features_in_area(g, u[i], v[i], radius[i], -1, -1, vIndices.data());
+        const int nPredictedLevel = level[i];
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < n; k++) {
+            const int idx = vIndices[k];
+            const int kpLevel = g->koct[idx];
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (use_chi2) {
+                if (uright && uright[idx] >= 0) {            /* :914-927 */
+                    const float ex = u[i] - g->kx[idx], ey = v[i] - g->ky[idx], er = ur[i] - uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {                                     /* :928-938 */
+                    const float ex = u[i] - g->kx[idx], ey = v[i] - g->ky[idx];
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = hamming(qdesc + (size_t)i * 32, kdesc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= 50) {   /* TH_LOW, :952 / :1082 */
+            best_idx[i] = bestIdx;
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+/* ORBmatcher::SearchBySim3 from the window searches on (:1188-1325).  Side-1 query a belongs to keypoint q1_index[a] of KF1 and
+ * is searched in KF2's grid (g2), side-2 queries the other way round; match12[i1] = idx2 for mutual best matches, else -1. */
+int orc_search_by_sim3(const orc_grid *g1, const uint8_t *kdesc1, const orc_grid *g2, const uint8_t *kdesc2, int nq1,
+                       const int32_t *q1_index, const float *u1, const float *v1, const float *radius1, const int32_t *level1,
+                       const uint8_t *qdesc1, int nq2, const int32_t *q2_index, const float *u2, const float *v2,
+                       const float *radius2, const int32_t *level2, const uint8_t *qdesc2, int32_t *match12) {
+    const int N1 = (int)g1->kx.size(), N2 = (int)g2->kx.size();
+    std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+    for (int a = 0; a < nq1; a++) {   /* :1188-1224 */
+        int bestDist;
+        const int bestIdx = window_best(g2, kdesc2, nullptr, u1[a], v1[a], radius1[a], level1[a] - 1, level1[a], false,
+                                        qdesc1 + (size_t)a * 32, &bestDist);
+        if (bestIdx >= 0 && bestDist <= 100) vnMatch1[q1_index[a]] = bestIdx;   /* TH_HIGH */
+    }
+    for (int a = 0; a < nq2; a++) {   /* :1268-1304 */
+        int bestDist;
+        const int bestIdx = window_best(g1, kdesc1, nullptr, u2[a], v2[a], radius2[a], level2[a] - 1, level2[a], false,
+                                        qdesc2 + (size_t)a * 32, &bestDist);
+        if (bestIdx >= 0 && bestDist <= 100) vnMatch2[q2_index[a]] = bestIdx;
+    }
+    int nFound = 0;                   /* :1307-1323 */
+    for (int i1 = 0; i1 < N1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) {
+            match12[i1] = idx2;
+            nFound++;
+        }
+    }
+    return nFound;
+}
+
+/* ORBmatcher::SearchForInitialization (:405-520).  g2 / kdesc2 / kangle2 / kxy2: F2's grid, descriptors, angles, mvKeysUn[*].pt;
+ * side 1: F1.mvKeysUn octaves and angles, F1.mDescriptors; prev_xy = vbPrevMatched (updated at the end, :514-517). */
+int orc_search_for_initialization(const orc_grid *g2, const uint8_t *kdesc2, const float *kangle2, int n1, const int32_t *oct1,
+                                  const float *angle1, const uint8_t *desc1, float *prev_xy, int window_size, float nn_ratio,
+                                  int check_orientation, int32_t *vnMatches12) {
+    const int HISTO_LENGTH = 30;
+    const int n2 = (int)g2->kx.size();
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+    std::vector<int32_t> vIndices2(n2 + 1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = oct1[i1];
+        if (level1 > 0) continue;
+        const int n = orc_features_in_area(g2, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)window_size, level1, level1, vIndices2.data());
+        if (n == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int k = 0; k < n; k++) {
+            const int i2 = vIndices2[k];
+            const int dist = hamming(desc1 + (size_t)i1 * 32, kdesc2 + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= 50) {
+            if (bestDist < (float)bestDist2 * nn_ratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    vnMatches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = angle1[i1] - kangle2[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[30], ind[3];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int32_t)rotHist[i].size();
+        orc_three_maxima(sizes, HISTO_LENGTH, ind);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (int idx1 : rotHist[i])
+                if (vnMatches12[idx1] >= 0) {
+                    vnMatches12[idx1] = -1;
+                    nmatches--;
+                }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)      /* :514-517 */
+        if (vnMatches12[i1] >= 0) {
+            prev_xy[2 * i1] = g2->kx[vnMatches12[i1]];
+            prev_xy[2 * i1 + 1] = g2->ky[vnMatches12[i1]];
+        }
+    return nmatches;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine (:140-157); F12 row-major 3x3 */
+static bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, int oct2, const float *F12, const float *levelSigma2) {
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * levelSigma2[oct2];
+}
+
+/* ORBmatcher::SearchForTriangulation (:657-823) after the epipole has been computed (:664-670: ex, ey).  The shared nodes
+ * come as in orc_search_by_bow.  has_mp1 / has_mp2: GetMapPoint(idx) != NULL; uright1 / uright2: mvuRight; xy*: mvKeysUn[*].pt;
+ * vMatches12[idx1] = idx2 or -1 (the vMatchedPairs of :812-820 are its non-negative entries in index order). */
+int orc_search_for_triangulation(const uint8_t *desc1, const uint8_t *has_mp1, const float *uright1, const float *xy1,
+                                 const float *angle1, int n1, const uint8_t *desc2, const uint8_t *has_mp2, const float *uright2,
+                                 const float *xy2, const int32_t *oct2, const float *angle2, int n2, const int32_t *off1,
+                                 const int32_t *idx1, const int32_t *off2, const int32_t *idx2, int n_nodes, const float *F12,
+                                 float ex, float ey, const float *scale_factors, const float *level_sigma2, int only_stereo,
+                                 int check_orientation, int32_t *vMatches12) {
+    const int HISTO_LENGTH = 30;
+    const int TH_LOW = 50;
+    int nmatches = 0;
+    std::vector<char> vbMatched2((size_t)std::max(n2, 1), 0);   /* never set in the reference either (:677, :725) */
+    for (int i = 0; i < n1; i++) vMatches12[i] = -1;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int k = 0; k < n_nodes; k++) {
+        for (int a = off1[k]; a < off1[k + 1]; a++) {
+            const int i1 = idx1[a];
+            if (has_mp1[i1]) continue;                                   /* :699-703 */
+            const bool bStereo1 = uright1[i1] >= 0;
+            if (only_stereo && !bStereo1) continue;
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int b = off2[k]; b < off2[k + 1]; b++) {
+                const int i2 = idx2[b];
+                if (vbMatched2[i2] || has_mp2[i2]) continue;             /* :725 */
+                const bool bStereo2 = uright2[i2] >= 0;
+                if (only_stereo && !bStereo2) continue;
+                const int dist = hamming(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                if (dist > TH_LOW || dist > bestDist) continue;          /* :738 */
+                if (!bStereo1 && !bStereo2) {                            /* :743-749 */
+                    const float distex = ex - xy2[2 * i2], distey = ey - xy2[2 * i2 + 1];
+                    if (distex * distex + distey * distey < 100 * scale_factors[oct2[i2]]) continue;
+                }
+                if (check_dist_epipolar_line(xy1[2 * i1], xy1[2 * i1 + 1], xy2[2 * i2], xy2[2 * i2 + 1], oct2[i2], F12, level_sigma2)) {
+                    bestIdx2 = i2;
+                    bestDist = dist;
+                }
+            }
+            if (bestIdx2 >= 0) {
+                vMatches12[i1] = bestIdx2;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = angle1[i1] - angle2[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[30], ind[3];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int32_t)rotHist[i].size();
+        orc_three_maxima(sizes, HISTO_LENGTH, ind);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (int j : rotHist[i]) {
+                vMatches12[j] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 /* ------------------------------------------------------------ SearchByBoW (src/ORBmatcher.cc:159-288, :522-655) */
 /* The loops over one shared node after the other, as the reference's merge walk visits them; see include/orbfe.h
  * (orbfe_search_by_bow) for the argument meaning. */

@@ -129,6 +129,31 @@ void orc_search_by_bow(const uint8_t *desc1, const uint8_t *valid1, int n1, cons
 void orc_three_maxima(const int32_t *sizes, int L, int32_t ind[3]);
 int orc_rotation_filter(const float *angle1, const float *angle2, int32_t *match1, int n1);
 
+/* the remaining guided searches from their window search on; see orb_oracle.cpp for the reference lines */
+int orc_search_by_projection_sim3(const orc_grid *g, const uint8_t *kdesc, int nq, const float *u, const float *v,
+                                  const float *radius, const int32_t *level, const uint8_t *qdesc, uint8_t *matched,
+                                  int32_t *match_idx);
+int orc_search_by_projection_reloc(const orc_grid *g, const uint8_t *kdesc, const float *kangle, int nq, const float *u,
+                                   const float *v, const float *radius, const int32_t *level, const float *qangle,
+                                   const uint8_t *qdesc, int orb_dist, int check_orientation, uint8_t *occupied,
+                                   int32_t *assigned);
+int orc_fuse_select(const orc_grid *g, const uint8_t *kdesc, const float *uright, const float *inv_level_sigma2, int use_chi2,
+                    int nq, const float *u, const float *v, const float *ur, const float *radius, const int32_t *level,
+                    const uint8_t *qdesc, int32_t *best_idx);
+int orc_search_by_sim3(const orc_grid *g1, const uint8_t *kdesc1, const orc_grid *g2, const uint8_t *kdesc2, int nq1,
+                       const int32_t *q1_index, const float *u1, const float *v1, const float *radius1, const int32_t *level1,
+                       const uint8_t *qdesc1, int nq2, const int32_t *q2_index, const float *u2, const float *v2,
+                       const float *radius2, const int32_t *level2, const uint8_t *qdesc2, int32_t *match12);
+int orc_search_for_initialization(const orc_grid *g2, const uint8_t *kdesc2, const float *kangle2, int n1, const int32_t *oct1,
+                                  const float *angle1, const uint8_t *desc1, float *prev_xy, int window_size, float nn_ratio,
+                                  int check_orientation, int32_t *vnMatches12);
+int orc_search_for_triangulation(const uint8_t *desc1, const uint8_t *has_mp1, const float *uright1, const float *xy1,
+                                 const float *angle1, int n1, const uint8_t *desc2, const uint8_t *has_mp2, const float *uright2,
+                                 const float *xy2, const int32_t *oct2, const float *angle2, int n2, const int32_t *off1,
+                                 const int32_t *idx1, const int32_t *off2, const int32_t *idx2, int n_nodes, const float *F12,
+                                 float ex, float ey, const float *scale_factors, const float *level_sigma2, int only_stereo,
+                                 int check_orientation, int32_t *vMatches12);
+
 /* time n_frames calls of orc_extract over `threads` threads (one frame per thread at a time); returns seconds */
 double orc_time_extract(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, const uint8_t *imgs, int n_frames,
                         int w, int h, int stride, long frame_stride, int threads, int reps, long *total_kps);

@@ -30,6 +30,7 @@ EXPORTS = [
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
     "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
+    "orbfe_search_area_ex", "orbfe_search_for_triangulation",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -43,6 +44,11 @@ class OrbfeParams(C.Structure):
 class OrbfeProfile(C.Structure):
     _fields_ = [("stage_ms", C.c_double * 5), ("stage_launches", C.c_int64 * 5), ("frames", C.c_int64),
                 ("candidates", C.c_int64), ("keypoints", C.c_int64)]
+
+
+class OrbfeAreaOptions(C.Structure):
+    _fields_ = [("blocked", C.c_void_p), ("dist_limit", C.c_void_p), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32),
+                ("pad", C.c_int32), ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double)]
 
 
 class OrbfeError(RuntimeError):
@@ -98,6 +104,9 @@ def lib():
     L.orbfe_frame_grid_destroy.argtypes = [vp]
     L.orbfe_search_area.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]
+    L.orbfe_search_area_ex.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(OrbfeAreaOptions), vp]
+    L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int,
+                                                 vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp]
     L.orbfe_matcher_synchronize.argtypes = [vp]
     L.orbfe_matcher_stream.restype = vp
     L.orbfe_matcher_stream.argtypes = [vp]
@@ -316,6 +325,25 @@ class ORBmatcher:
                                           self.mfNNratio if nn_ratio is None else float(nn_ratio), _np_ptr(match1)))
         return match1[:len(d1)]
 
+    def search_for_triangulation(self, desc1, has_mp1, uright1, xy1, desc2, has_mp2, uright2, xy2, oct2, off1, idx1, off2, idx2,
+                                 F12, ex, ey, scale_factors, level_sigma2, only_stereo=False):
+        """SearchForTriangulation loops of src/ORBmatcher.cc:691-789 over shared nodes (host arrays in, vMatches12 out)."""
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+        u1, u2 = np.ascontiguousarray(uright1, np.float32), np.ascontiguousarray(uright2, np.float32)
+        x1, x2 = np.ascontiguousarray(xy1, np.float32), np.ascontiguousarray(xy2, np.float32)
+        o2 = np.ascontiguousarray(oct2, np.int32)
+        f1, i1, f2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf, s2 = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+        match1 = np.zeros(max(len(d1), 1), np.int32)
+        check(self._L.orbfe_search_for_triangulation(self._h, _np_ptr(d1), _np_ptr(h1), _np_ptr(u1), _np_ptr(x1), len(d1), _np_ptr(d2),
+                                                     _np_ptr(h2), _np_ptr(u2), _np_ptr(x2), _np_ptr(o2), len(d2), _np_ptr(f1),
+                                                     _np_ptr(i1), _np_ptr(f2), _np_ptr(i2), len(f1) - 1, _np_ptr(F), float(ex),
+                                                     float(ey), _np_ptr(sf), _np_ptr(s2), len(sf), 1 if only_stereo else 0,
+                                                     _np_ptr(match1)))
+        return match1[:len(d1)]
+
     def synchronize(self):
         check(self._L.orbfe_matcher_synchronize(self._h))
 
@@ -350,6 +378,20 @@ class FrameGrid:
         res = np.zeros(len(q), AREA_RESULT_DTYPE)
         check(self._L.orbfe_search_area(matcher._h, self._h, _np_ptr(q), _np_ptr(d), len(q), None if b is None else _np_ptr(b),
                                         _np_ptr(res)))
+        return res
+
+    def search_ex(self, matcher: "ORBmatcher", queries: np.ndarray, qdesc: np.ndarray, blocked=None, dist_limit=None,
+                  inv_level_sigma2=None, chi2_mono=5.99, chi2_stereo=7.8) -> np.ndarray:
+        """orbfe_search_area_ex: the window search with the skip mask, the vMatchedDistance limit and the Fuse gate."""
+        q = np.ascontiguousarray(queries, AREA_QUERY_DTYPE)
+        d = np.ascontiguousarray(qdesc, np.uint8)
+        b = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+        lim = None if dist_limit is None else np.ascontiguousarray(dist_limit, np.int32)
+        s2 = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        opt = OrbfeAreaOptions(None if b is None else b.ctypes.data, None if lim is None else lim.ctypes.data,
+                               None if s2 is None else s2.ctypes.data, 0 if s2 is None else len(s2), 0, chi2_mono, chi2_stereo)
+        res = np.zeros(len(q), AREA_RESULT_DTYPE)
+        check(self._L.orbfe_search_area_ex(matcher._h, self._h, _np_ptr(q), _np_ptr(d), len(q), C.byref(opt), _np_ptr(res)))
         return res
 
     def close(self):

@@ -492,6 +492,9 @@ struct AreaArgs {
     const uint4 *kdesc;          // [n][2]
     const float *uRight;         // may be null
     const uint8_t *blocked;      // may be null
+    const int32_t *distLimit;    // may be null: skip idx when distLimit[idx] <= dist (SearchForInitialization, src/ORBmatcher.cc:444)
+    const float *invSigma2;      // may be null: mvInvLevelSigma2, switches on the reprojection gate of Fuse (:914-938)
+    double chi2Mono, chi2Stereo; // 5.99 / 7.8
     float minX, minY, wInv, hInv;
     const AreaQuery *q;
     const uint4 *qdesc;          // [nq][2]
@@ -532,9 +535,22 @@ __global__ __launch_bounds__(64) void search_area_kernel(AreaArgs a) {
                         const float ur = a.uRight[idx];
                         if (ur > 0 && fabsf(__fsub_rn(q.projXR, ur)) > q.erMax) continue;
                     }
+                    if (a.invSigma2) {                                  // Fuse, :914-938: u = q.x, v = q.y, ur = q.projXR
+                        const float ex = __fsub_rn(q.x, a.kx[idx]), ey = __fsub_rn(q.y, a.ky[idx]);
+                        float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        const float kpr = a.uRight ? a.uRight[idx] : -1.0f;
+                        double lim = a.chi2Mono;
+                        if (kpr >= 0) {
+                            const float er = __fsub_rn(q.projXR, kpr);
+                            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                            lim = a.chi2Stereo;
+                        }
+                        if ((double)__fmul_rn(e2, a.invSigma2[oct]) > lim) continue;
+                    }
                     const uint4 d0 = a.kdesc[2 * (size_t)idx], d1 = a.kdesc[2 * (size_t)idx + 1];
                     const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
                                      __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+                    if (a.distLimit && a.distLimit[idx] <= dist) continue;   // :444
                     if (dist < out.bestDist) {                          // :100-113
                         out.bestDist2 = out.bestDist; out.bestDist = dist;
                         out.bestLevel2 = out.bestLevel; out.bestLevel = oct;
@@ -628,6 +644,71 @@ __global__ __launch_bounds__(64) void bow_match_kernel(BowMatchArgs a) {
             }
         }
         __syncthreads();                                   // one wave per workgroup: orders the LDS update before the next scan
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SearchForTriangulation (reference src/ORBmatcher.cc:657-823): inside a shared vocabulary node every side-1 feature
+// without a MapPoint looks for the side-2 feature without a MapPoint that has the smallest distance <= TH_LOW among those
+// that pass the epipole test (:743-749) and CheckDistEpipolarLine (:140-157).  The reference accepts a candidate when
+// `dist <= bestDist` (:738), so of several candidates at the least distance the LAST in list order wins; vbMatched2 is
+// never set (:677, :725), so the loop has no dependency between side-1 features.  One wavefront per node, lanes split the
+// side-2 features; key = dist << 16 | (0xFFFF - position): the smallest key is that candidate.
+struct TriArgs {
+    const uint4 *desc1; const uint8_t *hasMp1; const float *uRight1; const float2 *xy1;
+    const uint4 *desc2; const uint8_t *hasMp2; const float *uRight2; const float2 *xy2; const int32_t *oct2;
+    const int32_t *off1, *idx1, *off2, *idx2;
+    float F12[9];                // row-major
+    float ex, ey;                // epipole in the second image (:664-670)
+    float scale[kMaxLevels], sigma2[kMaxLevels];
+    int onlyStereo;
+    int32_t *match1;             // [n1], preset to -1
+};
+
+__global__ __launch_bounds__(64) void triangulation_match_kernel(TriArgs a) {
+    const int node = blockIdx.x, lane = threadIdx.x;
+    const int b1 = a.off1[node], e1 = a.off1[node + 1], b2 = a.off2[node], e2 = a.off2[node + 1];
+    const int n2 = e2 - b2;
+    if (n2 <= 0 || e1 <= b1) return;
+    for (int i = b1; i < e1; i++) {
+        const int q = a.idx1[i];
+        if (a.hasMp1[q]) continue;                                           // :699-703
+        const bool bStereo1 = a.uRight1[q] >= 0;
+        if (a.onlyStereo && !bStereo1) continue;                             // :707-709
+        const uint4 q0 = a.desc1[2 * (size_t)q], q1 = a.desc1[2 * (size_t)q + 1];
+        const float2 p1 = a.xy1[q];
+        // l = x1' F12 (:143-145), every product and sum rounded on its own
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(p1.x, a.F12[0]), __fmul_rn(p1.y, a.F12[3])), a.F12[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(p1.x, a.F12[1]), __fmul_rn(p1.y, a.F12[4])), a.F12[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(p1.x, a.F12[2]), __fmul_rn(p1.y, a.F12[5])), a.F12[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        uint32_t best = 0xFFFFFFFFu;
+        for (int base = 0; base < n2; base += 64) {
+            const int pos = base + lane;
+            if (pos >= n2) continue;
+            const int j = a.idx2[b2 + pos];
+            if (a.hasMp2[j]) continue;                                       // :725
+            const bool bStereo2 = a.uRight2[j] >= 0;
+            if (a.onlyStereo && !bStereo2) continue;                         // :730-732
+            const uint4 d0 = a.desc2[2 * (size_t)j], d1 = a.desc2[2 * (size_t)j + 1];
+            const uint32_t dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                                  __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+            if (dist > 50u) continue;                                        // TH_LOW, :738
+            const float2 p2 = a.xy2[j];
+            const int o2 = a.oct2[j];
+            if (!bStereo1 && !bStereo2) {                                    // :743-749
+                const float dx = __fsub_rn(a.ex, p2.x), dy = __fsub_rn(a.ey, p2.y);
+                if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.0f, a.scale[o2])) continue;
+            }
+            if (den == 0) continue;                                          // :151-152
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, p2.x), __fmul_rn(lb, p2.y)), lc);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)a.sigma2[o2])) continue;     // :156
+            best = min(best, (dist << 16) | (uint32_t)(0xFFFF - pos));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+        if (lane == 0 && best != 0xFFFFFFFFu) a.match1[q] = a.idx2[b2 + (0xFFFF - (int)(best & 0xFFFFu))];
     }
 }
 

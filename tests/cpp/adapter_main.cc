@@ -6,6 +6,11 @@
 //                                                          adapter_main project case.bin out.bin
 //                                                          adapter_main bowmatch case.bin out.bin
 //                                                          adapter_main track case.bin out.bin
+//                                                          adapter_main guided case.bin out.bin
+//                                                          adapter_main triangulate case.bin out.bin
+// The guided mode runs the remaining window searches of orbfe::ProjectionSearch (searchSim3Projection, searchRelocalization,
+// fuseSelect, SearchBySim3, searchForInitialization) and the triangulate mode orbfe::TriangulationMatcher; layouts in
+// tests/test_guided_search.py.
 // The track mode runs orbfe::ProjectionSearch::searchLastFrame: SearchByProjection(CurrentFrame, LastFrame, th, bMono)
 // (src/ORBmatcher.cc:1328-1470) from the window search on.
 // The bowmatch mode runs orbfe::BowMatcher::SearchByBoW (src/ORBmatcher.cc:159-288 / :522-655) on two feature sets with
@@ -217,7 +222,139 @@ static int bowmatch_main(char **argv) {
     return 0;
 }
 
+namespace {
+struct GuidedSide {   // one frame / keyframe with its grid, plus the points searched in it
+    int n = 0, nq = 0;
+    std::vector<float> kx, ky, kur, kang, u, v, ur, radius, angle;
+    std::vector<int> oct, level, index;
+    std::vector<unsigned char> desc, occ, qd;
+    std::vector<cv::KeyPoint> keys;
+    std::vector<orbfe::ProjectionSearch::WindowPoint> pts;
+    bool read(FILE *fi) {
+        auto rd = [&](void *p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, fi) == bytes; };
+        if (!rd(&n, 4) || !rd(&nq, 4) || n < 0 || nq < 0) return false;
+        kx.resize(n); ky.resize(n); kur.resize(n); kang.resize(n); oct.resize(n); desc.resize((size_t)n * 32 + 1); occ.resize(n);
+        u.resize(nq); v.resize(nq); ur.resize(nq); radius.resize(nq); angle.resize(nq); level.resize(nq); index.resize(nq);
+        qd.resize((size_t)nq * 32 + 1);
+        const size_t a = 4 * (size_t)n, b = 4 * (size_t)nq;
+        if (!(rd(kx.data(), a) && rd(ky.data(), a) && rd(oct.data(), a) && rd(kur.data(), a) && rd(kang.data(), a) &&
+              rd(desc.data(), 32 * (size_t)n) && rd(occ.data(), n) && rd(u.data(), b) && rd(v.data(), b) && rd(ur.data(), b) &&
+              rd(radius.data(), b) && rd(level.data(), b) && rd(angle.data(), b) && rd(index.data(), b) && rd(qd.data(), 32 * (size_t)nq)))
+            return false;
+        keys.resize(n);
+        for (int i = 0; i < n; i++) {
+            keys[i].pt.x = kx[i]; keys[i].pt.y = ky[i]; keys[i].octave = oct[i]; keys[i].angle = kang[i];
+        }
+        pts.resize(nq);
+        for (int i = 0; i < nq; i++)
+            pts[i] = {u[i], v[i], ur[i], radius[i], level[i], angle[i], qd.data() + (size_t)i * 32, index[i]};
+        return true;
+    }
+};
+}  // namespace
+
+static int guided_main(char **argv) {
+    FILE *fi = std::fopen(argv[2], "rb");
+    if (!fi) return 3;
+    int hdr[4];      // kind, checkOrientation, ORBdist / n1 (initialisation), use the Fuse gate
+    float f[3];      // mfGridElementWidthInv, mfGridElementHeightInv, nnratio
+    float invSigma2[8];
+    if (std::fread(hdr, 4, 4, fi) != 4 || std::fread(f, 4, 3, fi) != 3 || std::fread(invSigma2, 4, 8, fi) != 8) return 3;
+    GuidedSide A, B;
+    if (!A.read(fi)) return 3;
+    const int kind = hdr[0];
+    if (kind == 4 && !B.read(fi)) return 3;
+    std::fclose(fi);
+    orbfe::ProjectionSearch psA, psB;
+    cv::Mat DA(A.n, 32, CV_8UC1, A.desc.data(), (size_t)32);
+    if (psA.build(A.keys, DA, A.kur, 0.0f, 0.0f, f[0], f[1]) != 0) { std::fprintf(stderr, "guided: %s\n", orbfe_last_error()); return 5; }
+    std::vector<int> out1;
+    std::vector<unsigned char> out2;
+    int count = 0, rc = 0;
+    if (kind == 1) {
+        out2 = A.occ;
+        rc = psA.searchSim3Projection(A.pts, out2, out1, &count);
+    } else if (kind == 2) {
+        out2 = A.occ;
+        rc = psA.searchRelocalization(A.pts, A.kang, hdr[2], hdr[1] != 0, out2, out1, &count);
+    } else if (kind == 3) {
+        std::vector<float> s2;
+        if (hdr[3]) s2.assign(invSigma2, invSigma2 + 8);
+        rc = psA.fuseSelect(A.pts, s2, out1, &count);
+    } else if (kind == 4) {
+        cv::Mat DB(B.n, 32, CV_8UC1, B.desc.data(), (size_t)32);
+        if (psB.build(B.keys, DB, B.kur, 0.0f, 0.0f, f[0], f[1]) != 0) return 5;
+        // A.pts: MapPoints of KF1 (= side A) searched in KF2's grid (side B); B.pts the other way round
+        rc = orbfe::ProjectionSearch::SearchBySim3(psA, psB, A.pts, B.pts, out1, &count);
+    } else if (kind == 5) {
+        rc = psA.searchForInitialization(A.pts, hdr[2], A.kang, f[2], hdr[1] != 0, out1, &count);
+    } else {
+        return 2;
+    }
+    if (rc != 0) { std::fprintf(stderr, "guided: %s\n", orbfe_last_error()); return 6; }
+    FILE *fo = std::fopen(argv[3], "wb");
+    if (!fo) return 4;
+    const int rq = (int)psA.requeried(), n1 = (int)out1.size(), n2 = (int)out2.size();
+    std::fwrite(&count, 4, 1, fo);
+    std::fwrite(&rq, 4, 1, fo);
+    std::fwrite(&n1, 4, 1, fo);
+    std::fwrite(&n2, 4, 1, fo);
+    std::fwrite(out1.data(), 4, n1, fo);
+    std::fwrite(out2.data(), 1, n2, fo);
+    std::fclose(fo);
+    std::printf("adapter guided ok: kind %d, %d points, count %d, %d searched again\n", kind, A.nq, count, rq);
+    return 0;
+}
+
+static int triangulate_main(char **argv) {
+    FILE *fi = std::fopen(argv[2], "rb");
+    if (!fi) return 3;
+    int hdr[6];      // n1, n2, entries on side 1 and 2, bOnlyStereo, checkOrientation
+    float F[9], e[2], sf[8], s2[8];
+    if (std::fread(hdr, 4, 6, fi) != 6 || std::fread(F, 4, 9, fi) != 9 || std::fread(e, 4, 2, fi) != 2 || std::fread(sf, 4, 8, fi) != 8 ||
+        std::fread(s2, 4, 8, fi) != 8)
+        return 3;
+    const int n1 = hdr[0], n2 = hdr[1], e1 = hdr[2], e2 = hdr[3];
+    std::vector<unsigned char> d1((size_t)n1 * 32 + 1), d2((size_t)n2 * 32 + 1), mp1(n1), mp2(n2);
+    std::vector<float> x1(n1), y1(n1), a1(n1), u1(n1), x2(n2), y2(n2), a2(n2), u2(n2);
+    std::vector<int> o2(n2), ent1((size_t)e1 * 2 + 1), ent2((size_t)e2 * 2 + 1);
+    auto rd = [&](void *p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, fi) == bytes; };
+    const size_t a = 4 * (size_t)n1, b = 4 * (size_t)n2;
+    const bool ok = rd(d1.data(), 32 * (size_t)n1) && rd(mp1.data(), n1) && rd(u1.data(), a) && rd(x1.data(), a) && rd(y1.data(), a) &&
+                    rd(a1.data(), a) && rd(d2.data(), 32 * (size_t)n2) && rd(mp2.data(), n2) && rd(u2.data(), b) && rd(x2.data(), b) &&
+                    rd(y2.data(), b) && rd(a2.data(), b) && rd(o2.data(), b) && rd(ent1.data(), 8 * (size_t)e1) &&
+                    rd(ent2.data(), 8 * (size_t)e2);
+    std::fclose(fi);
+    if (!ok) return 3;
+    orbfe::TriangulationMatcher::FeatureVector fv1, fv2;
+    for (int i = 0; i < e1; i++) fv1[(unsigned)ent1[2 * i]].push_back((unsigned)ent1[2 * i + 1]);
+    for (int i = 0; i < e2; i++) fv2[(unsigned)ent2[2 * i]].push_back((unsigned)ent2[2 * i + 1]);
+    std::vector<cv::KeyPoint> k1(n1), k2(n2);
+    for (int i = 0; i < n1; i++) { k1[i].pt.x = x1[i]; k1[i].pt.y = y1[i]; k1[i].angle = a1[i]; }
+    for (int i = 0; i < n2; i++) { k2[i].pt.x = x2[i]; k2[i].pt.y = y2[i]; k2[i].angle = a2[i]; k2[i].octave = o2[i]; }
+    cv::Mat D1(n1, 32, CV_8UC1, d1.data(), (size_t)32), D2(n2, 32, CV_8UC1, d2.data(), (size_t)32);
+    orbfe::TriangulationMatcher tm;
+    std::vector<std::pair<size_t, size_t> > pairs;
+    int nmatches = 0;
+    if (tm.SearchForTriangulation(fv1, D1, k1, mp1, u1, fv2, D2, k2, mp2, u2, F, e[0], e[1], std::vector<float>(sf, sf + 8),
+                                  std::vector<float>(s2, s2 + 8), hdr[4] != 0, hdr[5] != 0, pairs, &nmatches) != 0) {
+        std::fprintf(stderr, "triangulate: %s\n", orbfe_last_error());
+        return 6;
+    }
+    FILE *fo = std::fopen(argv[3], "wb");
+    if (!fo) return 4;
+    const int np = (int)pairs.size();
+    std::fwrite(&nmatches, 4, 1, fo);
+    std::fwrite(&np, 4, 1, fo);
+    for (auto &pr : pairs) { int v[2] = {(int)pr.first, (int)pr.second}; std::fwrite(v, 4, 2, fo); }
+    std::fclose(fo);
+    std::printf("adapter triangulate ok: %d x %d features, %d pairs\n", n1, n2, np);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 4 && std::strcmp(argv[1], "guided") == 0) return guided_main(argv);
+    if (argc >= 4 && std::strcmp(argv[1], "triangulate") == 0) return triangulate_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "bowmatch") == 0) return bowmatch_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "track") == 0) return track_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "project") == 0) return project_main(argv);

@@ -80,6 +80,15 @@ def lib():
         L.orc_three_maxima.restype = None
         L.orc_rotation_filter.argtypes = [f32p, f32p, i32p, C.c_int]
         L.orc_rotation_filter.restype = C.c_int
+        vp_, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.orc_search_by_projection_sim3.argtypes = [vp_, u8p, ci, f32p, f32p, f32p, i32p, u8p, u8p, i32p]
+        L.orc_search_by_projection_reloc.argtypes = [vp_, u8p, f32p, ci, f32p, f32p, f32p, i32p, f32p, u8p, ci, ci, u8p, i32p]
+        L.orc_fuse_select.argtypes = [vp_, u8p, f32p, f32p, ci, ci, f32p, f32p, f32p, f32p, i32p, u8p, i32p]
+        L.orc_search_by_sim3.argtypes = [vp_, u8p, vp_, u8p, ci, i32p, f32p, f32p, f32p, i32p, u8p, ci, i32p, f32p, f32p, f32p, i32p,
+                                         u8p, i32p]
+        L.orc_search_for_initialization.argtypes = [vp_, u8p, f32p, ci, i32p, f32p, u8p, f32p, ci, cf, ci, i32p]
+        L.orc_search_for_triangulation.argtypes = [u8p, u8p, f32p, f32p, f32p, ci, u8p, u8p, f32p, f32p, i32p, f32p, ci, i32p, i32p,
+                                                   i32p, i32p, ci, f32p, cf, cf, f32p, f32p, ci, ci, i32p]
         L.orc_distinctive.argtypes = [u8p, i32p, C.c_int, i32p]
         L.orc_distinctive.restype = None
         L.orc_bow_descend.argtypes = [i32p, i32p, u8p, C.c_int, u8p, C.c_int, C.c_int, i32p, i32p]
@@ -341,6 +350,85 @@ class OracleGrid:
                               None if b is None else _ptr(b, u8p), x, y, r, min_level, max_level, proj_xr, er_max, _ptr(q, u8p),
                               _ptr(res, i32p))
         return res
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dt)
+
+
+def search_by_projection_sim3(g: "OracleGrid", u, v, radius, level, qdesc, matched):
+    """SearchByProjection(KeyFrame*, Scw, ...) (src/ORBmatcher.cc:359-399); returns (match_idx, matched_after, nmatches)."""
+    u, v, radius, level, qd = _c(u, np.float32), _c(v, np.float32), _c(radius, np.float32), _c(level, np.int32), _c(qdesc, np.uint8)
+    m = _c(matched, np.uint8).copy()
+    out = np.zeros(max(len(u), 1), np.int32)
+    n = lib().orc_search_by_projection_sim3(g.h, _ptr(g.kdesc, u8p), len(u), _ptr(u, f32p), _ptr(v, f32p), _ptr(radius, f32p),
+                                            _ptr(level, i32p), _ptr(qd, u8p), _ptr(m, u8p), _ptr(out, i32p))
+    return out[:len(u)], m, n
+
+
+def search_by_projection_reloc(g: "OracleGrid", kangle, u, v, radius, level, qangle, qdesc, orb_dist, check_ori, occupied):
+    """SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (:1525-1598); returns (assigned, occupied, n)."""
+    ka, u, v, radius = _c(kangle, np.float32), _c(u, np.float32), _c(v, np.float32), _c(radius, np.float32)
+    level, qa, qd = _c(level, np.int32), _c(qangle, np.float32), _c(qdesc, np.uint8)
+    occ = _c(occupied, np.uint8).copy()
+    out = np.zeros(max(len(g.kx), 1), np.int32)
+    n = lib().orc_search_by_projection_reloc(g.h, _ptr(g.kdesc, u8p), _ptr(ka, f32p), len(u), _ptr(u, f32p), _ptr(v, f32p),
+                                             _ptr(radius, f32p), _ptr(level, i32p), _ptr(qa, f32p), _ptr(qd, u8p), int(orb_dist),
+                                             int(check_ori), _ptr(occ, u8p), _ptr(out, i32p))
+    return out[:len(g.kx)], occ, n
+
+
+def fuse_select(g: "OracleGrid", inv_level_sigma2, use_chi2, u, v, ur, radius, level, qdesc):
+    """selection part of both Fuse overloads (:889-952 / :1048-1082); returns (best_idx, nFused)."""
+    s2, u, v, ur = _c(inv_level_sigma2, np.float32), _c(u, np.float32), _c(v, np.float32), _c(ur, np.float32)
+    radius, level, qd = _c(radius, np.float32), _c(level, np.int32), _c(qdesc, np.uint8)
+    out = np.zeros(max(len(u), 1), np.int32)
+    n = lib().orc_fuse_select(g.h, _ptr(g.kdesc, u8p), None if g.uright is None else _ptr(g.uright, f32p), _ptr(s2, f32p),
+                              int(use_chi2), len(u), _ptr(u, f32p), _ptr(v, f32p), _ptr(ur, f32p), _ptr(radius, f32p),
+                              _ptr(level, i32p), _ptr(qd, u8p), _ptr(out, i32p))
+    return out[:len(u)], n
+
+
+def search_by_sim3(g1: "OracleGrid", g2: "OracleGrid", q1, q2):
+    """SearchBySim3 (:1188-1325); q = (index, u, v, radius, level, qdesc) per direction; returns (match12, nFound)."""
+    def prep(q):
+        return (_c(q[0], np.int32), _c(q[1], np.float32), _c(q[2], np.float32), _c(q[3], np.float32), _c(q[4], np.int32),
+                _c(q[5], np.uint8))
+    a, b = prep(q1), prep(q2)
+    out = np.zeros(max(len(g1.kx), 1), np.int32)
+    n = lib().orc_search_by_sim3(g1.h, _ptr(g1.kdesc, u8p), g2.h, _ptr(g2.kdesc, u8p), len(a[0]), _ptr(a[0], i32p), _ptr(a[1], f32p),
+                                 _ptr(a[2], f32p), _ptr(a[3], f32p), _ptr(a[4], i32p), _ptr(a[5], u8p), len(b[0]), _ptr(b[0], i32p),
+                                 _ptr(b[1], f32p), _ptr(b[2], f32p), _ptr(b[3], f32p), _ptr(b[4], i32p), _ptr(b[5], u8p),
+                                 _ptr(out, i32p))
+    return out[:len(g1.kx)], n
+
+
+def search_for_initialization(g2: "OracleGrid", kangle2, oct1, angle1, desc1, prev_xy, window_size, nn_ratio, check_ori):
+    """SearchForInitialization (:405-520); returns (vnMatches12, prev_xy_after, nmatches)."""
+    ka, o1, a1, d1 = _c(kangle2, np.float32), _c(oct1, np.int32), _c(angle1, np.float32), _c(desc1, np.uint8)
+    pxy = _c(prev_xy, np.float32).copy()
+    out = np.zeros(max(len(o1), 1), np.int32)
+    n = lib().orc_search_for_initialization(g2.h, _ptr(g2.kdesc, u8p), _ptr(ka, f32p), len(o1), _ptr(o1, i32p), _ptr(a1, f32p),
+                                            _ptr(d1, u8p), _ptr(pxy, f32p), int(window_size), float(nn_ratio), int(check_ori),
+                                            _ptr(out, i32p))
+    return out[:len(o1)], pxy, n
+
+
+def search_for_triangulation(desc1, has_mp1, uright1, xy1, angle1, desc2, has_mp2, uright2, xy2, oct2, angle2, off1, idx1, off2,
+                             idx2, F12, ex, ey, scale_factors, level_sigma2, only_stereo, check_ori):
+    """SearchForTriangulation (:657-823); returns (vMatches12, nmatches)."""
+    d1, d2, h1, h2 = _c(desc1, np.uint8), _c(desc2, np.uint8), _c(has_mp1, np.uint8), _c(has_mp2, np.uint8)
+    u1, u2, x1, x2 = _c(uright1, np.float32), _c(uright2, np.float32), _c(xy1, np.float32), _c(xy2, np.float32)
+    a1, a2, o2 = _c(angle1, np.float32), _c(angle2, np.float32), _c(oct2, np.int32)
+    f1, i1, f2, i2 = (_c(a, np.int32) for a in (off1, idx1, off2, idx2))
+    F, sf, s2 = _c(F12, np.float32).reshape(9), _c(scale_factors, np.float32), _c(level_sigma2, np.float32)
+    out = np.zeros(max(len(d1), 1), np.int32)
+    n = lib().orc_search_for_triangulation(_ptr(d1, u8p), _ptr(h1, u8p), _ptr(u1, f32p), _ptr(x1, f32p), _ptr(a1, f32p), len(d1),
+                                           _ptr(d2, u8p), _ptr(h2, u8p), _ptr(u2, f32p), _ptr(x2, f32p), _ptr(o2, i32p),
+                                           _ptr(a2, f32p), len(d2), _ptr(f1, i32p), _ptr(i1, i32p), _ptr(f2, i32p), _ptr(i2, i32p),
+                                           len(f1) - 1, _ptr(F, f32p), float(ex), float(ey), _ptr(sf, f32p), _ptr(s2, f32p),
+                                           int(only_stereo), int(check_ori), _ptr(out, i32p))
+    return out[:len(d1)], n
 
 
 def search_by_bow(desc1, valid1, desc2, blocked2, off1, idx1, off2, idx2, max_dist, nn_ratio):

@@ -1,0 +1,529 @@
+"""The remaining guided searches of ORBmatcher from their window search on:
+SearchByProjection(KeyFrame*, Scw, ...) (reference src/ORBmatcher.cc:290-403), SearchByProjection(Frame&, KeyFrame*, ...)
+(:1472-1599), Fuse x2 (:825-975, :977-1100), SearchBySim3 (:1102-1326), SearchForInitialization (:405-520) and
+SearchForTriangulation (:657-823).
+
+CPU part: the oracle's C++ restatements against independent numpy restatements (brute-force windows, sorting instead of
+scanning).  GPU part: the C-ABI entry points (orbfe_search_area_ex, orbfe_search_for_triangulation) and the C++ adapters of
+include/ORBmatcher_orbfe.h (through tests/cpp/adapter_main) against the oracle, association for association.
+"""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import oracle_lib as O  # noqa: E402
+from orb_slam2_amd import synth  # noqa: E402
+
+POP = np.array([bin(i).count("1") for i in range(256)], np.int32)
+W, H = 1241, 376
+W_INV, H_INV = np.float32(64) / np.float32(W), np.float32(48) / np.float32(H)
+SF = np.ones(8, np.float32)
+for _i in range(1, 8):
+    SF[_i] = SF[_i - 1] * np.float32(1.2)                       # ORBextractor.cc:417-421
+SIGMA2 = (SF * SF).astype(np.float32)                           # mvLevelSigma2 (:424)
+INV_SIGMA2 = (np.float32(1.0) / SIGMA2).astype(np.float32)      # mvInvLevelSigma2 (:431)
+
+_frames = {}
+
+
+def frame(seed):
+    """keypoints and descriptors of one synthetic KITTI-sized image, from the oracle extractor (cached)."""
+    if seed not in _frames:
+        img = synth.textured_image(W, H, synth.BASE_SEED + seed)
+        k, d = O.OracleExtractor(2000, 1.2, 8, 20, 7).extract(img)
+        rng = np.random.default_rng(seed)
+        n = len(k)
+        ur = np.where(rng.uniform(size=n) < 0.5, k["x"] - rng.uniform(1, 60, n), -1).astype(np.float32)
+        _frames[seed] = dict(kx=k["x"].copy(), ky=k["y"].copy(), oct=k["octave"].astype(np.int32), ang=k["angle"].copy(), d=d.copy(),
+                             ur=ur, n=n)
+    return _frames[seed]
+
+
+def grid(F):
+    return O.OracleGrid(F["kx"], F["ky"], F["oct"], F["d"], F["ur"], 0.0, 0.0, float(W_INV), float(H_INV))
+
+
+def noisy(d, rng, flips):
+    out = d.copy()
+    for i in range(len(out)):
+        for b in rng.integers(0, 256, flips if np.isscalar(flips) else int(rng.integers(*flips))):
+            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
+
+
+def points(F, rng, nq, th, jitter=4.0, level_up=(0, 2), subset=None):
+    """map points that project near keypoints of F: what the host part of a guided search hands to its window search."""
+    src = rng.integers(0, F["n"], nq) if subset is None else rng.choice(subset, nq)
+    u = (F["kx"][src] + rng.uniform(-jitter, jitter, nq)).astype(np.float32)
+    v = (F["ky"][src] + rng.uniform(-jitter, jitter, nq)).astype(np.float32)
+    ur = np.where(F["ur"][src] >= 0, F["ur"][src] + rng.uniform(-2, 2, nq), u - 20).astype(np.float32)
+    level = np.clip(F["oct"][src] + rng.integers(level_up[0], level_up[1], nq), 0, 7).astype(np.int32)
+    radius = (np.float32(th) * SF[level]).astype(np.float32)
+    ang = np.mod(np.where(rng.uniform(size=nq) < 0.85, F["ang"][src] + 15 + rng.normal(0, 2, nq), rng.uniform(0, 360, nq)),
+                 360).astype(np.float32)
+    return dict(u=u, v=v, ur=ur, radius=radius, level=level, ang=ang, d=noisy(F["d"][src], rng, 10), src=src, nq=nq,
+                index=np.zeros(nq, np.int32))
+
+
+# ------------------------------------------------------------------ independent numpy restatements (CPU KATs) ---------
+
+def window(F, x, y, r):
+    """KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:569-608) by brute force, in grid order (cell column, cell row, index)."""
+    x, y, r = np.float32(x), np.float32(y), np.float32(r)
+    posx = np.round(F["kx"] * W_INV).astype(int)
+    posy = np.round(F["ky"] * H_INV).astype(int)
+    cx0, cx1 = max(0, int(np.floor((x - r) * W_INV))), min(63, int(np.ceil((x + r) * W_INV)))
+    cy0, cy1 = max(0, int(np.floor((y - r) * H_INV))), min(47, int(np.ceil((y + r) * H_INV)))
+    ok = (posx >= cx0) & (posx <= cx1) & (posy >= cy0) & (posy <= cy1) & (posx < 64) & (posy < 48)
+    ok &= (np.abs(F["kx"] - x) < r) & (np.abs(F["ky"] - y) < r)
+    idx = np.nonzero(ok)[0]
+    return idx[np.lexsort((idx, posy[idx], posx[idx]))]
+
+
+def first_min(F, cand, q):
+    if len(cand) == 0:
+        return 256, -1
+    d = POP[F["d"][cand] ^ q[None, :]].sum(1)
+    j = int(np.argmin(d))                                       # first minimum = the reference's strict '<' scan
+    return int(d[j]), int(cand[j])
+
+
+def test_oracle_sim3_projection_and_relocalization_vs_numpy():
+    F = frame(11)
+    rng = np.random.default_rng(1)
+    P = points(F, rng, 2600, 4.0)
+    g = grid(F)
+    occ = (rng.uniform(size=F["n"]) < 0.1).astype(np.uint8)
+    # SearchByProjection(pKF, Scw, ...): levels [L-1, L], accepted up to TH_LOW, accepted keypoints blocked
+    got, occ_after, n = O.search_by_projection_sim3(g, P["u"], P["v"], P["radius"], P["level"], P["d"], occ)
+    blocked = occ.astype(bool).copy()
+    want = np.full(P["nq"], -1, np.int32)
+    for i in range(P["nq"]):
+        c = window(F, P["u"][i], P["v"][i], P["radius"][i])
+        c = c[(~blocked[c]) & (F["oct"][c] >= P["level"][i] - 1) & (F["oct"][c] <= P["level"][i])]
+        bd, bi = first_min(F, c, P["d"][i])
+        if bd <= 50:
+            want[i] = bi
+            blocked[bi] = True
+    assert np.array_equal(got, want) and n == (want >= 0).sum() and np.array_equal(occ_after.astype(bool), blocked)
+    assert n > 800 and len(np.unique(want[want >= 0])) == n
+    # SearchByProjection(CurrentFrame, pKF, ...): levels [L-1, L+1], ORBdist, the histogram un-assigns and frees keypoints
+    for orb_dist, check in ((100, True), (64, False)):
+        assigned, occ_after, n = O.search_by_projection_reloc(g, F["ang"], P["u"], P["v"], P["radius"], P["level"], P["ang"], P["d"],
+                                                              orb_dist, check, occ)
+        blocked = occ.astype(bool).copy()
+        want = np.full(F["n"], -1, np.int32)
+        for i in range(P["nq"]):
+            c = window(F, P["u"][i], P["v"][i], P["radius"][i])
+            c = c[(~blocked[c]) & (F["oct"][c] >= P["level"][i] - 1) & (F["oct"][c] <= P["level"][i] + 1)]
+            bd, bi = first_min(F, c, P["d"][i])
+            if bd <= orb_dist:
+                want[bi] = i
+                blocked[bi] = True
+        before = int((want >= 0).sum())
+        if check:
+            m = np.where(want >= 0, np.arange(F["n"]), -1).astype(np.int32)      # keypoint -> itself, to reuse the filter:
+            a1 = np.zeros(F["n"], np.float32)                                   # angle1[k] = angle of the point assigned to k
+            a1[want >= 0] = P["ang"][want[want >= 0]]
+            m, _ = O.rotation_filter(a1, F["ang"], m)
+            dropped = (want >= 0) & (m < 0)
+            want[dropped] = -1
+            blocked[dropped] = False
+        assert np.array_equal(assigned, want) and n == (want >= 0).sum() and np.array_equal(occ_after.astype(bool), blocked)
+        assert n > 800 and (not check or n < before)
+
+
+def test_oracle_fuse_and_sim3_vs_numpy():
+    F = frame(12)
+    rng = np.random.default_rng(2)
+    P = points(F, rng, 1500, 3.0, jitter=3.0)
+    g = grid(F)
+    for use_chi2 in (1, 0):
+        got, n = O.fuse_select(g, INV_SIGMA2, use_chi2, P["u"], P["v"], P["ur"], P["radius"], P["level"], P["d"])
+        want = np.full(P["nq"], -1, np.int32)
+        gated = 0
+        for i in range(P["nq"]):
+            c = window(F, P["u"][i], P["v"][i], P["radius"][i])
+            c = c[(F["oct"][c] >= P["level"][i] - 1) & (F["oct"][c] <= P["level"][i])]
+            if use_chi2 and len(c):
+                ex, ey = P["u"][i] - F["kx"][c], P["v"][i] - F["ky"][c]
+                er = P["ur"][i] - F["ur"][c]
+                stereo = F["ur"][c] >= 0
+                e2 = np.where(stereo, (ex * ex + ey * ey) + er * er, ex * ex + ey * ey).astype(np.float32)
+                keep = (e2 * INV_SIGMA2[F["oct"][c]]).astype(np.float64) <= np.where(stereo, 7.8, 5.99)
+                gated += int((~keep).sum())
+                c = c[keep]
+            bd, bi = first_min(F, c, P["d"][i])
+            if bd <= 50:
+                want[i] = bi
+        assert np.array_equal(got, want) and n == (want >= 0).sum() and n > 500
+        assert not use_chi2 or gated > 100
+    # SearchBySim3: both directions, mutual agreement
+    F2 = frame(13)
+    g2 = grid(F2)
+    n1, n2 = F["n"], F2["n"]
+    i1 = np.sort(rng.choice(n1, 900, replace=False)).astype(np.int32)      # KF1 keypoints with a MapPoint to project
+    i2 = np.sort(rng.choice(n2, 900, replace=False)).astype(np.int32)
+    # make the frames related: KF1's map point i1[a] really is KF2's keypoint t1[a] (descriptor copied with noise)
+    t1 = rng.integers(0, n2, len(i1))
+    Q1 = dict(u=(F2["kx"][t1] + rng.uniform(-3, 3, len(i1))).astype(np.float32), v=(F2["ky"][t1] + rng.uniform(-3, 3, len(i1))).astype(np.float32),
+              level=F2["oct"][t1].astype(np.int32), d=noisy(F2["d"][t1], rng, 8))
+    Q1["radius"] = (np.float32(7.5) * SF[Q1["level"]]).astype(np.float32)
+    # the other direction: KF2 keypoint i2[b] projects onto KF1 keypoint t2[b]; half of them are the mirror of direction 1
+    t2 = rng.integers(0, n1, len(i2))
+    mirror = rng.uniform(size=len(i2)) < 0.5
+    k = min(len(i1), len(i2))
+    i2[:k][mirror[:k]] = t1[:k][mirror[:k]]
+    t2[:k][mirror[:k]] = i1[:k][mirror[:k]]
+    Q2 = dict(u=(F["kx"][t2] + rng.uniform(-3, 3, len(i2))).astype(np.float32), v=(F["ky"][t2] + rng.uniform(-3, 3, len(i2))).astype(np.float32),
+              level=F["oct"][t2].astype(np.int32), d=noisy(F["d"][t2], rng, 8))
+    Q2["radius"] = (np.float32(7.5) * SF[Q2["level"]]).astype(np.float32)
+    got, n = O.search_by_sim3(g, g2, (i1, Q1["u"], Q1["v"], Q1["radius"], Q1["level"], Q1["d"]),
+                              (i2, Q2["u"], Q2["v"], Q2["radius"], Q2["level"], Q2["d"]))
+    m1, m2 = np.full(n1, -1), np.full(n2, -1)
+    for a in range(len(i1)):
+        c = window(F2, Q1["u"][a], Q1["v"][a], Q1["radius"][a])
+        c = c[(F2["oct"][c] >= Q1["level"][a] - 1) & (F2["oct"][c] <= Q1["level"][a])]
+        bd, bi = first_min(F2, c, Q1["d"][a])
+        if bd <= 100:
+            m1[i1[a]] = bi
+    for b in range(len(i2)):
+        c = window(F, Q2["u"][b], Q2["v"][b], Q2["radius"][b])
+        c = c[(F["oct"][c] >= Q2["level"][b] - 1) & (F["oct"][c] <= Q2["level"][b])]
+        bd, bi = first_min(F, c, Q2["d"][b])
+        if bd <= 100:
+            m2[i2[b]] = bi
+    want = np.array([m1[i] if m1[i] >= 0 and m2[m1[i]] == i else -1 for i in range(n1)], np.int32)
+    assert np.array_equal(got, want) and n == (want >= 0).sum() and n > 100 and (m1 >= 0).sum() > n
+
+
+def init_case(rng, F2, n1):
+    lvl0 = np.nonzero(F2["oct"] == 0)[0]
+    src = rng.choice(lvl0, n1)                                      # with repetition: several F1 keypoints want one F2 keypoint
+    oct1 = np.where(rng.uniform(size=n1) < 0.8, 0, rng.integers(1, 8, n1)).astype(np.int32)
+    prev = np.stack([F2["kx"][src] + rng.uniform(-30, 30, n1), F2["ky"][src] + rng.uniform(-30, 30, n1)], 1).astype(np.float32)
+    ang1 = np.mod(np.where(rng.uniform(size=n1) < 0.85, F2["ang"][src] + 8 + rng.normal(0, 2, n1), rng.uniform(0, 360, n1)), 360).astype(np.float32)
+    return dict(oct1=oct1, prev=prev, ang1=ang1, d1=noisy(F2["d"][src], rng, (0, 30)), n1=n1)
+
+
+def test_oracle_search_for_initialization_vs_numpy():
+    F2 = frame(14)
+    rng = np.random.default_rng(3)
+    C = init_case(rng, F2, 1800)
+    g2 = grid(F2)
+    for check, ratio in ((True, 0.9), (False, 0.8)):
+        got, prev_after, n = O.search_for_initialization(g2, F2["ang"], C["oct1"], C["ang1"], C["d1"], C["prev"], 100, ratio, check)
+        vmd = np.full(F2["n"], np.iinfo(np.int32).max, np.int64)
+        m12, m21 = np.full(C["n1"], -1, np.int32), np.full(F2["n"], -1, np.int32)
+        hist = [[] for _ in range(30)]
+        stolen = 0
+        for i in range(C["n1"]):
+            if C["oct1"][i] > 0:
+                continue
+            c = window(F2, C["prev"][i, 0], C["prev"][i, 1], 100.0)
+            c = c[F2["oct"][c] == 0]
+            if len(c) == 0:
+                continue
+            d = POP[F2["d"][c] ^ C["d1"][i][None, :]].sum(1)
+            live = vmd[c] > d
+            c, d = c[live], d[live]
+            order = np.argsort(d, kind="stable")
+            best = int(d[order[0]]) if len(c) else 2 ** 31 - 1
+            second = int(d[order[1]]) if len(c) > 1 else 2 ** 31 - 1
+            if best <= 50 and best < float(np.float32(np.float32(second) * np.float32(ratio))):
+                b = int(c[order[0]])
+                if m21[b] >= 0:
+                    m12[m21[b]] = -1
+                    stolen += 1
+                m12[i], m21[b], vmd[b] = b, i, best
+                rot = np.float32(C["ang1"][i]) - np.float32(F2["ang"][b])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360))
+                v = float(np.float32(rot * np.float32(1.0 / 30)))
+                bn = int(np.floor(v + 0.5))
+                hist[0 if bn == 30 else bn].append(i)
+        before = int((m12 >= 0).sum())
+        if check:
+            keep = set(O.three_maxima([len(h) for h in hist]))
+            for bn in range(30):
+                if bn not in keep:
+                    for i in hist[bn]:
+                        m12[i] = -1
+        assert np.array_equal(got, m12) and n == (m12 >= 0).sum() and stolen > 20
+        assert n > 300 and (not check or n < before)
+        live = got >= 0
+        assert np.array_equal(prev_after[live, 0], F2["kx"][got[live]]) and np.array_equal(prev_after[~live], C["prev"][~live])
+
+
+def tri_case(rng, F2, n1):
+    """KF2 = frame F2; KF1 = its keypoints seen from a camera shifted along x: same row up to noise, F12 = [t]x-like."""
+    n2 = F2["n"]
+    src = rng.integers(0, n2, n1)
+    x1 = (F2["kx"][src] + rng.uniform(5, 60, n1)).astype(np.float32)
+    y1 = (F2["ky"][src] + rng.normal(0, 1.2, n1) * SF[F2["oct"][src]]).astype(np.float32)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 2e-5, (3, 3)).astype(np.float32)
+    node2 = rng.integers(0, 90, n2) * 3
+    node1 = node2[src].copy()
+    stray = rng.uniform(size=n1) < 0.1
+    node1[stray] = rng.integers(0, 300, int(stray.sum()))
+    # the epipole sits on the densest spot of KF2; the keypoints around it are mono and free on both sides, so the epipole
+    # test (:743-749) has something to reject
+    dens = [(np.hypot(F2["kx"] - F2["kx"][i], F2["ky"] - F2["ky"][i]) < 10).sum() for i in range(n2)]
+    c = int(np.argmax(dens))
+    ex, ey = np.float32(F2["kx"][c] + 0.5), np.float32(F2["ky"][c] - 0.5)
+    near2 = np.hypot(F2["kx"] - ex, F2["ky"] - ey) < 12
+    ur2, mp2 = F2["ur"].copy(), (rng.uniform(size=n2) < 0.3).astype(np.uint8)
+    ur2[near2], mp2[near2] = -1, 0
+    ur1, mp1 = np.where(rng.uniform(size=n1) < 0.5, x1 - 10, -1).astype(np.float32), (rng.uniform(size=n1) < 0.3).astype(np.uint8)
+    ur1[near2[src]], mp1[near2[src]] = -1, 0
+    return dict(d1=noisy(F2["d"][src], rng, (0, 45)), mp1=mp1, ur1=ur1, xy1=np.stack([x1, y1], 1).astype(np.float32),
+                ang1=np.mod(np.where(rng.uniform(size=n1) < 0.85, F2["ang"][src] + 25 + rng.normal(0, 2, n1), rng.uniform(0, 360, n1)), 360).astype(np.float32),
+                mp2=mp2, ur2=ur2, F12=F12, ex=ex, ey=ey, node1=node1, node2=node2, n1=n1, src=src)
+
+
+def shared_nodes(node1, node2):
+    shared = sorted(set(node1.tolist()) & set(node2.tolist()))
+    l1 = [np.nonzero(node1 == k)[0] for k in shared]
+    l2 = [np.nonzero(node2 == k)[0] for k in shared]
+    off1 = np.concatenate([[0], np.cumsum([len(x) for x in l1])]).astype(np.int32)
+    off2 = np.concatenate([[0], np.cumsum([len(x) for x in l2])]).astype(np.int32)
+    return off1, np.concatenate(l1).astype(np.int32), off2, np.concatenate(l2).astype(np.int32)
+
+
+def test_oracle_search_for_triangulation_vs_numpy():
+    F2 = frame(15)
+    rng = np.random.default_rng(4)
+    C = tri_case(rng, F2, 1900)
+    off1, idx1, off2, idx2 = shared_nodes(C["node1"], C["node2"])
+    xy2 = np.stack([F2["kx"], F2["ky"]], 1).astype(np.float32)
+    for only_stereo in (0, 1):
+        got, n = O.search_for_triangulation(C["d1"], C["mp1"], C["ur1"], C["xy1"], C["ang1"], F2["d"], C["mp2"], C["ur2"], xy2,
+                                            F2["oct"], F2["ang"], off1, idx1, off2, idx2, C["F12"], C["ex"], C["ey"], SF, SIGMA2,
+                                            only_stereo, 0)
+        want = np.full(C["n1"], -1, np.int32)
+        F = C["F12"]
+        epi_rejects = epipole_rejects = 0
+        for k in range(len(off1) - 1):
+            c2 = idx2[off2[k]:off2[k + 1]]
+            for a in idx1[off1[k]:off1[k + 1]]:
+                st1 = C["ur1"][a] >= 0
+                if C["mp1"][a] or (only_stereo and not st1):
+                    continue
+                c = c2[C["mp2"][c2] == 0]
+                st2 = C["ur2"][c] >= 0
+                if only_stereo:
+                    c, st2 = c[st2], st2[st2]
+                d = POP[F2["d"][c] ^ C["d1"][a][None, :]].sum(1)
+                x1, y1 = C["xy1"][a]
+                la = np.float32(np.float32(x1 * F[0, 0]) + np.float32(y1 * F[1, 0])) + F[2, 0]
+                lb = np.float32(np.float32(x1 * F[0, 1]) + np.float32(y1 * F[1, 1])) + F[2, 1]
+                lc = np.float32(np.float32(x1 * F[0, 2]) + np.float32(y1 * F[1, 2])) + F[2, 2]
+                num = ((la * xy2[c, 0]).astype(np.float32) + (lb * xy2[c, 1]).astype(np.float32)).astype(np.float32) + lc
+                den = np.float32(np.float32(la * la) + np.float32(lb * lb))
+                dsqr = ((num * num).astype(np.float32) / den).astype(np.float32)
+                epi = dsqr.astype(np.float64) < 3.84 * SIGMA2[F2["oct"][c]].astype(np.float64)
+                dx, dy = C["ex"] - xy2[c, 0], C["ey"] - xy2[c, 1]
+                near = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32) < (np.float32(100) * SF[F2["oct"][c]])
+                near &= (not st1) & (~st2)
+                ok = (d <= 50) & epi & ~near
+                epi_rejects += int(((d <= 50) & ~epi).sum())
+                epipole_rejects += int(((d <= 50) & near).sum())
+                if ok.any():
+                    dm = d[ok].min()
+                    want[a] = int(c[np.nonzero(ok & (d == dm))[0][-1]])          # `dist > bestDist` at :738: the last of equals wins
+        assert np.array_equal(got, want) and n == (want >= 0).sum()
+        assert n > (60 if only_stereo else 150) and epi_rejects > 50 and (only_stereo or epipole_rejects > 0)
+    # the histogram on top: same as the filter on the unfiltered result
+    got0, n0 = O.search_for_triangulation(C["d1"], C["mp1"], C["ur1"], C["xy1"], C["ang1"], F2["d"], C["mp2"], C["ur2"], xy2, F2["oct"],
+                                          F2["ang"], off1, idx1, off2, idx2, C["F12"], C["ex"], C["ey"], SF, SIGMA2, 0, 0)
+    got1, n1 = O.search_for_triangulation(C["d1"], C["mp1"], C["ur1"], C["xy1"], C["ang1"], F2["d"], C["mp2"], C["ur2"], xy2, F2["oct"],
+                                          F2["ang"], off1, idx1, off2, idx2, C["F12"], C["ex"], C["ey"], SF, SIGMA2, 0, 1)
+    ref, nref = O.rotation_filter(C["ang1"], F2["ang"], got0.copy())
+    assert np.array_equal(got1, ref) and n1 == nref < n0
+
+
+# ------------------------------------------------------------------ GPU: C-ABI and C++ adapters against the oracle ------
+
+EXE = ROOT / "tests" / "cpp" / "adapter_main"
+
+
+def write_side(fh, F, P, occ):
+    fh.write(np.array([F["n"], P["nq"]], np.int32).tobytes())
+    for a in (F["kx"], F["ky"], F["oct"], F["ur"], F["ang"], F["d"], occ, P["u"], P["v"], P["ur"], P["radius"], P["level"], P["ang"],
+              P["index"].astype(np.int32), P["d"]):
+        fh.write(np.ascontiguousarray(a).tobytes())
+
+
+def run_guided(tmp_path, kind, sides, check_ori=0, third=0, use_gate=0, ratio=0.9):
+    case, out = tmp_path / "case.bin", tmp_path / "out.bin"
+    with open(case, "wb") as fh:
+        fh.write(np.array([kind, check_ori, third, use_gate], np.int32).tobytes())
+        fh.write(np.array([W_INV, H_INV, ratio], np.float32).tobytes())
+        fh.write(INV_SIGMA2.tobytes())
+        for F, P, occ in sides:
+            write_side(fh, F, P, occ)
+    r = subprocess.run([str(EXE), "guided", str(case), str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    count, rq, n1, n2 = np.frombuffer(buf, np.int32, 4)
+    return int(count), int(rq), np.frombuffer(buf, np.int32, n1, 16), np.frombuffer(buf, np.uint8, n2, 16 + 4 * n1)
+
+
+@pytest.mark.gpu
+def test_cpp_sim3_projection_replays_the_reference_loop(tmp_path):
+    F = frame(21)
+    rng = np.random.default_rng(5)
+    P = points(F, rng, 2600, 4.0)
+    occ = (rng.uniform(size=F["n"]) < 0.1).astype(np.uint8)
+    count, rq, match_idx, occ_out = run_guided(tmp_path, 1, [(F, P, occ)])
+    want, occ_want, n = O.search_by_projection_sim3(grid(F), P["u"], P["v"], P["radius"], P["level"], P["d"], occ)
+    assert np.array_equal(match_idx, want) and count == n and np.array_equal(occ_out, occ_want)
+    assert n > 800 and rq > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orb_dist,check_ori", [(100, 1), (64, 1), (100, 0)])
+def test_cpp_relocalization_projection_replays_the_reference_loop(tmp_path, orb_dist, check_ori):
+    F = frame(22)
+    rng = np.random.default_rng(6 + orb_dist)
+    P = points(F, rng, 2400, 10.0 if orb_dist == 100 else 3.0, level_up=(-1, 2))
+    occ = (rng.uniform(size=F["n"]) < 0.15).astype(np.uint8)
+    count, rq, assigned, occ_out = run_guided(tmp_path, 2, [(F, P, occ)], check_ori=check_ori, third=orb_dist)
+    want, occ_want, n = O.search_by_projection_reloc(grid(F), F["ang"], P["u"], P["v"], P["radius"], P["level"], P["ang"], P["d"],
+                                                     orb_dist, check_ori, occ)
+    assert np.array_equal(assigned, want) and count == n and np.array_equal(occ_out, occ_want)
+    assert n > 700 and rq > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_gate", [1, 0])
+def test_cpp_fuse_selection_matches_oracle(tmp_path, use_gate):
+    F = frame(23)
+    rng = np.random.default_rng(7)
+    P = points(F, rng, 3000, 3.0, jitter=3.0)
+    count, _, best, _ = run_guided(tmp_path, 3, [(F, P, np.zeros(F["n"], np.uint8))], use_gate=use_gate)
+    want, n = O.fuse_select(grid(F), INV_SIGMA2, use_gate, P["u"], P["v"], P["ur"], P["radius"], P["level"], P["d"])
+    assert np.array_equal(best, want) and count == n and n > 1000
+    other, _ = O.fuse_select(grid(F), INV_SIGMA2, 1 - use_gate, P["u"], P["v"], P["ur"], P["radius"], P["level"], P["d"])
+    assert not np.array_equal(want, other)                         # the reprojection gate really changes the outcome
+
+
+@pytest.mark.gpu
+def test_cpp_search_by_sim3_matches_oracle(tmp_path):
+    F1, F2 = frame(24), frame(25)
+    rng = np.random.default_rng(8)
+    n1, n2 = F1["n"], F2["n"]
+    i1 = np.sort(rng.choice(n1, 1000, replace=False)).astype(np.int32)
+    t1 = rng.integers(0, n2, len(i1))
+    P1 = dict(u=(F2["kx"][t1] + rng.uniform(-3, 3, len(i1))).astype(np.float32), v=(F2["ky"][t1] + rng.uniform(-3, 3, len(i1))).astype(np.float32),
+              level=F2["oct"][t1].astype(np.int32), d=noisy(F2["d"][t1], rng, 8), index=i1, nq=len(i1))
+    # the other direction mirrors direction 1 for 60 % of the pairs (distinct KF2 keypoints), the rest is unrelated
+    pairs = {}
+    for a in range(len(i1)):
+        pairs.setdefault(int(t1[a]), int(i1[a]))
+    keys = np.array(sorted(pairs), np.int32)
+    keep = keys[rng.uniform(size=len(keys)) < 0.6]
+    extra = np.setdiff1d(rng.choice(n2, 300, replace=False), keys).astype(np.int32)
+    i2 = np.concatenate([keep, extra]).astype(np.int32)
+    t2 = np.concatenate([np.array([pairs[int(k)] for k in keep], np.int32), rng.integers(0, n1, len(extra)).astype(np.int32)])
+    order = np.argsort(i2)
+    i2, t2 = i2[order], t2[order]
+    P2 = dict(u=(F1["kx"][t2] + rng.uniform(-3, 3, len(i2))).astype(np.float32), v=(F1["ky"][t2] + rng.uniform(-3, 3, len(i2))).astype(np.float32),
+              level=F1["oct"][t2].astype(np.int32), d=noisy(F1["d"][t2], rng, 8), index=i2, nq=len(i2))
+    for P in (P1, P2):
+        P["radius"] = (np.float32(7.5) * SF[P["level"]]).astype(np.float32)
+        P["ur"] = np.zeros(P["nq"], np.float32)
+        P["ang"] = np.zeros(P["nq"], np.float32)
+    z1, z2 = np.zeros(n1, np.uint8), np.zeros(n2, np.uint8)
+    count, _, match12, _ = run_guided(tmp_path, 4, [(F1, P1, z1), (F2, P2, z2)])
+    want, n = O.search_by_sim3(grid(F1), grid(F2), (P1["index"], P1["u"], P1["v"], P1["radius"], P1["level"], P1["d"]),
+                               (P2["index"], P2["u"], P2["v"], P2["radius"], P2["level"], P2["d"]))
+    assert np.array_equal(match12, want) and count == n and 200 < n < len(i1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check_ori,ratio", [(1, 0.9), (0, 0.8)])
+def test_cpp_search_for_initialization_replays_the_reference_loop(tmp_path, check_ori, ratio):
+    F2 = frame(26)
+    rng = np.random.default_rng(9)
+    C = init_case(rng, F2, 1800)
+    lvl0 = np.nonzero(C["oct1"] == 0)[0].astype(np.int32)              # the adapter is handed the level-0 keypoints (:421-423)
+    P = dict(u=C["prev"][lvl0, 0].copy(), v=C["prev"][lvl0, 1].copy(), ur=np.zeros(len(lvl0), np.float32),
+             radius=np.full(len(lvl0), 100, np.float32), level=np.zeros(len(lvl0), np.int32), ang=C["ang1"][lvl0], index=lvl0,
+             d=C["d1"][lvl0], nq=len(lvl0))
+    count, rq, m12, _ = run_guided(tmp_path, 5, [(F2, P, np.zeros(F2["n"], np.uint8))], check_ori=check_ori, third=C["n1"], ratio=ratio)
+    want, _, n = O.search_for_initialization(grid(F2), F2["ang"], C["oct1"], C["ang1"], C["d1"], C["prev"], 100, ratio, check_ori)
+    assert np.array_equal(m12, want) and count == n
+    assert n > 300 and rq > 10                                          # contention for F2 keypoints occurred and was replayed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("only_stereo,check_ori", [(0, 1), (1, 1), (0, 0)])
+def test_cpp_search_for_triangulation_matches_oracle(tmp_path, only_stereo, check_ori):
+    F2 = frame(27)
+    rng = np.random.default_rng(10)
+    C = tri_case(rng, F2, 1900)
+    n1, n2 = C["n1"], F2["n"]
+    ent1 = np.stack([C["node1"], np.arange(n1)], 1).astype(np.int32)
+    ent2 = np.stack([C["node2"], np.arange(n2)], 1).astype(np.int32)
+    case, out = tmp_path / "case.bin", tmp_path / "out.bin"
+    with open(case, "wb") as fh:
+        fh.write(np.array([n1, n2, n1, n2, only_stereo, check_ori], np.int32).tobytes())
+        fh.write(C["F12"].astype(np.float32).tobytes())
+        fh.write(np.array([C["ex"], C["ey"]], np.float32).tobytes())
+        fh.write(SF.tobytes())
+        fh.write(SIGMA2.tobytes())
+        for a in (C["d1"], C["mp1"], C["ur1"], C["xy1"][:, 0], C["xy1"][:, 1], C["ang1"], F2["d"], C["mp2"], C["ur2"], F2["kx"], F2["ky"],
+                  F2["ang"], F2["oct"], ent1, ent2):
+            fh.write(np.ascontiguousarray(a).tobytes())
+    r = subprocess.run([str(EXE), "triangulate", str(case), str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = out.read_bytes()
+    nmatches, npairs = np.frombuffer(buf, np.int32, 2)
+    pairs = np.frombuffer(buf, np.int32, 2 * npairs, 8).reshape(-1, 2)
+    off1, idx1, off2, idx2 = shared_nodes(C["node1"], C["node2"])
+    xy2 = np.stack([F2["kx"], F2["ky"]], 1).astype(np.float32)
+    want, n = O.search_for_triangulation(C["d1"], C["mp1"], C["ur1"], C["xy1"], C["ang1"], F2["d"], C["mp2"], C["ur2"], xy2, F2["oct"],
+                                         F2["ang"], off1, idx1, off2, idx2, C["F12"], C["ex"], C["ey"], SF, SIGMA2, only_stereo, check_ori)
+    live = np.nonzero(want >= 0)[0]
+    assert nmatches == n == npairs and np.array_equal(pairs[:, 0], live) and np.array_equal(pairs[:, 1], want[live])
+    assert n > (60 if only_stereo else 150)
+
+
+@pytest.mark.gpu
+def test_search_area_ex_options_match_oracle():
+    """orbfe_search_area_ex through ctypes: the vMatchedDistance limit and the Fuse gate, query by query against the oracle's
+    loops; bad arguments are refused."""
+    from orb_slam2_amd import capi
+    F = frame(28)
+    rng = np.random.default_rng(12)
+    P = points(F, rng, 800, 3.0, jitter=3.0)
+    m = capi.ORBmatcher(device=0)
+    fg = capi.FrameGrid(F["kx"], F["ky"], F["oct"], F["d"], F["ur"], 0.0, 0.0, float(W_INV), float(H_INV))
+    q = np.zeros(P["nq"], capi.AREA_QUERY_DTYPE)
+    q["x"], q["y"], q["r"], q["min_level"], q["max_level"], q["proj_xr"], q["er_max"] = P["u"], P["v"], P["radius"], P["level"] - 1, P["level"], P["ur"], -1
+    res = fg.search_ex(m, q, P["d"], inv_level_sigma2=INV_SIGMA2)
+    want, _ = O.fuse_select(grid(F), INV_SIGMA2, 1, P["u"], P["v"], P["ur"], P["radius"], P["level"], P["d"])
+    got = np.where(res["best_dist"] <= 50, res["best_idx"], -1)
+    assert np.array_equal(got, want)
+    # the limit: keypoint idx is skipped when limit[idx] <= dist; limit 0 skips it always, INT_MAX never
+    limit = rng.choice(np.array([0, 20, 60, 2 ** 31 - 1], np.int32), F["n"]).astype(np.int32)
+    res = fg.search_ex(m, q, P["d"], dist_limit=limit)
+    for i in range(0, P["nq"], 7):
+        c = window(F, P["u"][i], P["v"][i], P["radius"][i])
+        c = c[(F["oct"][c] >= P["level"][i] - 1) & (F["oct"][c] <= P["level"][i])]
+        d = POP[F["d"][c] ^ P["d"][i][None, :]].sum(1)
+        live = limit[c] > d
+        order = np.argsort(d[live], kind="stable")
+        exp = (int(d[live][order[0]]), int(c[live][order[0]])) if live.any() else (256, -1)
+        assert (int(res["best_dist"][i]), int(res["best_idx"][i])) == exp
+        assert int(res["best_dist2"][i]) == (int(d[live][order[1]]) if live.sum() > 1 else 256)
+    with pytest.raises(capi.OrbfeError):
+        fg.search_ex(m, q, P["d"], inv_level_sigma2=INV_SIGMA2[:3])      # octaves up to 7 would index past the table
