@@ -206,6 +206,38 @@ def other_configs(local_rank, dev):
     out["search_by_bow_1500x2000_100_nodes"] = {"latency_ms_host_arrays_to_host_matches": round(float(np.median(lat)) * 1e3, 4),
                                                 "matches": int((mt >= 0).sum()),
                                                 "hamming_distances": int(sum((o1[k + 1] - o1[k]) * (o2[k + 1] - o2[k]) for k in range(nn)))}
+    # Fuse(KeyFrame*, vpMapPoints, th) selection (a-12): the same 1500 windows with th = 3 and the reprojection gate on the device
+    sf = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * np.float32(1.2)
+    sigma2 = (sf * sf).astype(np.float32)
+    q["r"] = (3.0 * sf[koct[src]]).astype(np.float32)
+    q["er_max"] = -1
+    inv_s2 = (np.float32(1) / sigma2).astype(np.float32)
+    res = grid.search_ex(m, q, qd, inv_level_sigma2=inv_s2)
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        res = grid.search_ex(m, q, qd, inv_level_sigma2=inv_s2)
+        lat.append(time.perf_counter() - t0)
+    out["fuse_selection_1500_windows"] = {"latency_ms_host_queries_to_host_results": round(float(np.median(lat)) * 1e3, 4),
+                                          "fused": int((res["best_dist"] <= 50).sum())}
+    # SearchForTriangulation loops (a-12): the same two feature sets and nodes, epipolar geometry of a sideways camera move
+    xy2 = rng.uniform([0, 0], [W, H], (n2, 2)).astype(np.float32)
+    xy1 = (xy2[srcb] + np.stack([rng.uniform(5, 60, n1), rng.normal(0, 1.0, n1)], 1)).astype(np.float32)
+    oct2 = rng.integers(0, 8, n2).astype(np.int32)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    z1, z2 = np.zeros(n1, np.uint8), np.zeros(n2, np.uint8)
+    u1, u2 = np.full(n1, -1, np.float32), np.full(n2, -1, np.float32)
+    tri = lambda: m.search_for_triangulation(d1, z1, u1, xy1, d2, z2, u2, xy2, oct2, o1, i1, o2, i2, F12, -500.0, 180.0, sf, sigma2)
+    mt = tri()
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        mt = tri()
+        lat.append(time.perf_counter() - t0)
+    out["search_for_triangulation_1500x2000_100_nodes"] = {"latency_ms_host_arrays_to_host_matches": round(float(np.median(lat)) * 1e3, 4),
+                                                           "matches": int((mt >= 0).sum())}
     return out
 
 

@@ -47,7 +47,37 @@ def oracle_digests():
     out["search_area"] = G.area_digest(np.array(rows, np.int32))
     d1, v1, d2, b2, (o1, i1), (o2, i2) = G.bowmatch_inputs()
     out["search_by_bow"] = G.bowmatch_digest(O.search_by_bow(d1, v1, d2, b2, o1, i1, o2, i2, G.BOWMATCH["max_dist"], G.BOWMATCH["ratio"]))
+    grid, fq, fqd, inv_sigma2, limit = G.fuse_inputs(*kitti)
+    og = O.OracleGrid(grid["kx"], grid["ky"], grid["koct"], kitti[1], grid["ur"], grid["min_x"], grid["min_y"], grid["w_inv"],
+                      grid["h_inv"])
+    best, _ = O.fuse_select(og, inv_sigma2, 1, fq["x"], fq["y"], fq["proj_xr"], fq["r"], fq["max_level"], fqd)
+    out["fuse"] = G.fuse_digest(best, limit_rows(og, fq, fqd, limit))
+    t = G.triangulation_inputs(*kitti)
+    zeros1, zeros2 = np.zeros(len(t["d1"]), np.float32), np.zeros(len(t["d2"]), np.float32)
+    tri = [O.search_for_triangulation(t["d1"], t["mp1"], t["ur1"], t["xy1"], zeros1, t["d2"], t["mp2"], t["ur2"], t["xy2"], t["oct2"],
+                                      zeros2, t["csr1"][0], t["csr1"][1], t["csr2"][0], t["csr2"][1], t["F12"], t["ex"], t["ey"],
+                                      t["sf"], t["sigma2"], only, 0)[0] for only in (0, 1)]
+    out["triangulation"] = G.triangulation_digest(*tri)
     return out
+
+
+def limit_rows(og, q, qd, limit):
+    """the candidate loop of SearchForInitialization (reference src/ORBmatcher.cc:436-457) per window, with `limit` as
+    vMatchedDistance: best / second over the candidates whose limit exceeds their distance, strict '<' in list order"""
+    rows = []
+    for i in range(len(qd)):
+        cand = og.features_in_area(float(q["x"][i]), float(q["y"][i]), float(q["r"][i]), int(q["min_level"][i]), int(q["max_level"][i]))
+        bd, bi, bd2, bi2 = 256, -1, 256, -1
+        for c in cand:
+            d = O.hamming(qd[i], og.kdesc[c])
+            if limit[c] <= d:
+                continue
+            if d < bd:
+                bd2, bi2, bd, bi = bd, bi, d, int(c)
+            elif d < bd2:
+                bd2, bi2 = d, int(c)
+        rows.append([bd, bi, bd2, bi2])
+    return np.array(rows, np.int32)
 
 
 if __name__ == "__main__":

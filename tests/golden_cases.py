@@ -28,6 +28,8 @@ BOW = dict(k=10, L=4, seed=17, n=3000, levelsup=2)
 DISTINCTIVE = dict(seed=18, points=400)
 AREA = dict(seed=19, nq=800)
 BOWMATCH = dict(seed=20, n1=1200, n2=1500, nodes=90, max_dist=50, ratio=0.7)
+FUSE = dict(seed=21, nq=1200)
+TRIANGULATION = dict(seed=22, n1=1500, nodes=80)
 
 
 def crc(a) -> int:
@@ -172,6 +174,85 @@ def bowmatch_inputs():
 def bowmatch_digest(match1):
     match1 = np.asarray(match1, np.int32)
     return {"sha256": sha(match1), "matches": int((match1 >= 0).sum()), "first_16": match1[:16].tolist()}
+
+
+def scale_tables():
+    sf = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * np.float32(1.2)
+    sigma2 = (sf * sf).astype(np.float32)
+    return sf, sigma2, (np.float32(1.0) / sigma2).astype(np.float32)
+
+
+def fuse_inputs(kps, desc):
+    """MapPoints projected near the keypoints of the KITTI extraction case, for the selection loop of
+    Fuse(KeyFrame*, vpMapPoints, th) (reference src/ORBmatcher.cc:889-952) and, with the limit array, the skip rule of
+    SearchForInitialization (:444)."""
+    c = EXTRACT_CASES["kitti_1241x376_2000"]
+    rng = np.random.default_rng(FUSE["seed"])
+    n, nq = len(kps), FUSE["nq"]
+    kx, ky, koct = kps["x"].copy(), kps["y"].copy(), kps["octave"].astype(np.int32)
+    sf, _, inv_sigma2 = scale_tables()
+    ur = np.where(rng.uniform(size=n) < 0.5, kx - rng.uniform(1, 60, n), -1).astype(np.float32)
+    src = rng.integers(0, n, nq)
+    q = {"x": (kx[src] + rng.uniform(-3, 3, nq)).astype(np.float32), "y": (ky[src] + rng.uniform(-3, 3, nq)).astype(np.float32)}
+    level = np.clip(koct[src] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+    q["r"] = (np.float32(3.0) * sf[level]).astype(np.float32)
+    q["min_level"], q["max_level"] = (level - 1).astype(np.int32), level
+    q["proj_xr"] = np.where(ur[src] >= 0, ur[src] + rng.uniform(-2, 2, nq), q["x"] - 20).astype(np.float32)
+    q["er_max"] = np.full(nq, -1, np.float32)
+    qd = desc[src].copy()
+    for i in range(nq):
+        for b in rng.integers(0, 256, 12):
+            qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    limit = rng.choice(np.array([0, 15, 40, 2 ** 31 - 1], np.int32), n).astype(np.int32)
+    grid = dict(kx=kx, ky=ky, koct=koct, ur=ur, min_x=0.0, min_y=0.0,
+                w_inv=float(np.float32(64) / np.float32(c["w"])), h_inv=float(np.float32(48) / np.float32(c["h"])))
+    return grid, q, qd, inv_sigma2, limit
+
+
+def fuse_digest(best_idx_gate, rows_limit):
+    """best_idx_gate: int32 [nq] keypoint fused into or -1; rows_limit: int32 [nq, 4] = best_dist, best_idx, best_dist2, best_idx2
+    of the search with the vMatchedDistance-style limit"""
+    a, b = np.asarray(best_idx_gate, np.int32), np.asarray(rows_limit, np.int32)
+    return {"gate_sha256": sha(a), "fused": int((a >= 0).sum()), "gate_first_16": a[:16].tolist(),
+            "limit_sha256": sha(b), "limit_first_8": b[:8].tolist()}
+
+
+def triangulation_inputs(kps, desc):
+    """SearchForTriangulation (:657-823): KF2 = the KITTI extraction case, KF1 = its keypoints seen from a camera shifted
+    along x (same row up to noise), features spread over vocabulary nodes."""
+    t = TRIANGULATION
+    rng = np.random.default_rng(t["seed"])
+    n2, n1 = len(kps), t["n1"]
+    sf, sigma2, _ = scale_tables()
+    x2, y2, oct2 = kps["x"].copy(), kps["y"].copy(), kps["octave"].astype(np.int32)
+    src = rng.integers(0, n2, n1)
+    x1 = (x2[src] + rng.uniform(5, 60, n1)).astype(np.float32)
+    y1 = (y2[src] + rng.normal(0, 1.2, n1) * sf[oct2[src]]).astype(np.float32)
+    d1 = desc[src].copy()
+    for i in range(n1):
+        for b in rng.integers(0, 256, int(rng.integers(0, 45))):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 2e-5, (3, 3))).astype(np.float32)
+    node2 = rng.integers(0, t["nodes"], n2)
+    node1 = node2[src].copy()
+    stray = rng.uniform(size=n1) < 0.1
+    node1[stray] = rng.integers(0, t["nodes"], int(stray.sum()))
+
+    def csr(node):
+        order = [np.nonzero(node == k)[0] for k in range(t["nodes"])]
+        return (np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32), np.concatenate(order).astype(np.int32))
+    return dict(d1=d1, mp1=(rng.uniform(size=n1) < 0.3).astype(np.uint8), ur1=np.where(rng.uniform(size=n1) < 0.5, x1 - 10, -1).astype(np.float32),
+                xy1=np.stack([x1, y1], 1).astype(np.float32), d2=desc, mp2=(rng.uniform(size=n2) < 0.3).astype(np.uint8),
+                ur2=np.where(rng.uniform(size=n2) < 0.5, x2 - 10, -1).astype(np.float32), xy2=np.stack([x2, y2], 1).astype(np.float32),
+                oct2=oct2, csr1=csr(node1), csr2=csr(node2), F12=F12, ex=float(x2[0]) + 0.5, ey=float(y2[0]) - 0.5, sf=sf, sigma2=sigma2)
+
+
+def triangulation_digest(m_all, m_stereo):
+    a, b = np.asarray(m_all, np.int32), np.asarray(m_stereo, np.int32)
+    return {"sha256": sha(np.stack([a, b])), "matches": int((a >= 0).sum()), "matches_only_stereo": int((b >= 0).sum()),
+            "first_pairs": [[int(i), int(a[i])] for i in np.nonzero(a >= 0)[0][:8]]}
 
 
 def load():

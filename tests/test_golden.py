@@ -27,7 +27,8 @@ def _diff(got, want, path=""):
 
 def test_golden_file_is_complete():
     g = G.load()
-    assert sorted(g) == ["bow_descend", "distinctive", "extract", "knn2", "search_area", "search_by_bow", "stereo"]
+    assert sorted(g) == ["bow_descend", "distinctive", "extract", "fuse", "knn2", "search_area", "search_by_bow", "stereo",
+                         "triangulation"]
     assert sorted(g["extract"]) == sorted(G.EXTRACT_CASES)
     k = g["extract"]["kitti_1241x376_2000"]
     # SURVEY.md section 8a check values: level sizes of 1241x376 at scale 1.2
@@ -35,6 +36,7 @@ def test_golden_file_is_complete():
                                                [416, 126], [346, 105]]
     assert 2000 <= k["keypoints"] <= 2000 + 3 * 8 and sum(l["kept"] for l in k["levels"]) == k["keypoints"]
     assert g["stereo"]["with_depth"] > 200 and g["search_area"]["with_match"] > 300
+    assert g["fuse"]["fused"] > 300 and g["triangulation"]["matches"] > g["triangulation"]["matches_only_stereo"] > 30
 
 
 def test_oracle_reproduces_golden():
@@ -114,3 +116,21 @@ def test_hip_path_reproduces_golden():
     d1, v1, d2, b2, (o1, i1), (o2, i2) = G.bowmatch_inputs()
     got = m.search_by_bow(d1, v1, d2, b2, o1, i1, o2, i2, G.BOWMATCH["max_dist"], G.BOWMATCH["ratio"])
     _diff(G.bowmatch_digest(got), want["search_by_bow"], "search_by_bow")
+    # Fuse selection (reprojection gate) and the vMatchedDistance limit on the window search
+    grid, fq, fqd, inv_sigma2, limit = G.fuse_inputs(*kitti)
+    fg = capi.FrameGrid(grid["kx"], grid["ky"], grid["koct"], kitti[1], grid["ur"], grid["min_x"], grid["min_y"], grid["w_inv"],
+                        grid["h_inv"])
+    qq = np.zeros(len(fqd), capi.AREA_QUERY_DTYPE)
+    for fld in ("x", "y", "r", "min_level", "max_level", "proj_xr", "er_max"):
+        qq[fld] = fq[fld]
+    res = fg.search_ex(m, qq, fqd, inv_level_sigma2=inv_sigma2)
+    best = np.where(res["best_dist"] <= 50, res["best_idx"], -1)
+    res = fg.search_ex(m, qq, fqd, dist_limit=limit)
+    rows = np.stack([res[fld] for fld in ("best_dist", "best_idx", "best_dist2", "best_idx2")], axis=1)
+    _diff(G.fuse_digest(best, rows), want["fuse"], "fuse")
+    # SearchForTriangulation loops
+    t = G.triangulation_inputs(*kitti)
+    tri = [m.search_for_triangulation(t["d1"], t["mp1"], t["ur1"], t["xy1"], t["d2"], t["mp2"], t["ur2"], t["xy2"], t["oct2"],
+                                      t["csr1"][0], t["csr1"][1], t["csr2"][0], t["csr2"][1], t["F12"], t["ex"], t["ey"], t["sf"],
+                                      t["sigma2"], only_stereo=bool(only)) for only in (0, 1)]
+    _diff(G.triangulation_digest(*tri), want["triangulation"], "triangulation")
