@@ -401,14 +401,16 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             hdt = float(tt.item())
         pairs = NQ * shard * world * hsteps
-        # integer-VALU roofline of the pair loop: 8 v_xor (full rate) + 8 v_bcnt + v_lshl_or + v_med3 + v_min (half rate).
-        # Rates measured on this chip by tools/ubench/valu_rates.hip (profiles/r1_valu_rates_ubench.txt):
-        # ~62 T lane-ops/s for v_xor/v_add, ~38 T lane-ops/s for v_bcnt / v_med3 / v_min / v_lshl_or.
-        peak_pairs = world / (8 / 62e12 + 11 / 38e12)
+        # integer-VALU roofline of the pair loop: XOR + popcount-accumulate of 8 dwords is 16 VALU instructions per wave and
+        # reference whatever else the kernel does, and a SIMD issues one wave64 VALU instruction per 4 cycles (measured:
+        # SQ_INSTS_VALU x 4 / kernel cycles = 99.6 %, profiles/r1e_pmc_summary.txt): 1024 SIMDs x 2.4 GHz / 4 / 16 x 64 lanes.
+        peak_pairs = world * 1024 * 2.4e9 / 4 / 16 * 64
         hamming = {"metric": "hamming_pair_distances_per_sec", "value": round(pairs / hdt, 1), "ms_per_query_batch": round(hdt / hsteps * 1e3, 3),
                    "queries": NQ, "database": shard * world, "shards": world,
                    "valu": {"achieved_Tpairs": round(pairs / hdt / 1e12, 3), "peak_Tpairs": round(peak_pairs / 1e12, 3),
-                            "frac": round(pairs / hdt / peak_pairs, 4), "lane_ops_per_pair": 19}}
+                            "frac": round(pairs / hdt / peak_pairs, 4), "valu_instructions_per_pair": 16.75,
+                            "note": "8 v_xor + 8 v_bcnt_u32_b32 (accumulating) + v_min3/v_min/v_cmp per 4 references; the best/second "
+                                    "selection runs only where a reference can still matter (sample-seeded threshold)"}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -52,8 +52,20 @@ __device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[8], const uin
 }
 
 // partial[chunk][nqPad] <- (best key, second key) of queries vs references [chunk*chunkLen, (chunk+1)*chunkLen)
+//
+// FILTER: the caller knows, per query, a distance T (seed[qi]) that at least two references of the WHOLE scan do not
+// exceed (the second-best distance over a sample of the database, knn2 pre-pass).  A reference with d > T can then be
+// neither the best nor the second-best of the whole scan, and inside a chunk a reference changes (best, second) only if
+// d < the chunk's running second distance (equal distance = later index = larger key).  So the selection -- three
+// half-rate VALU ops per pair -- is needed only where d < thr = min(T + 1, running second distance), which for a large
+// database is a few pairs in 10^4: the four distances of a trip are reduced with v_min3 / v_min, compared once, and the
+// wave branches around the selection unless some lane needs it.  Chunks may then report "none" (256) for a place that a
+// reference above T would have taken; the ordered fold of the chunks is unaffected because the final two places are held
+// by references <= T.
+template <bool FILTER>
 __global__ __launch_bounds__(256) void knn2_scan_kernel(const uint32_t *__restrict__ q, int nq, const uint32_t *__restrict__ r,
-                                                        int nr, int chunkLen, uint2 *__restrict__ partial, int nqPad) {
+                                                        int nr, int chunkLen, uint2 *__restrict__ partial, int nqPad,
+                                                        const int *__restrict__ seed) {
     const int qi = blockIdx.x * 256 + threadIdx.x;
     uint32_t qv[8];
     {
@@ -66,24 +78,44 @@ __global__ __launch_bounds__(256) void knn2_scan_kernel(const uint32_t *__restri
     const int n = min(chunkLen, nr - j0);
     const uint32_t *__restrict__ rp = r + (size_t)j0 * 8;
     uint32_t best = kKeyNone, second = kKeyNone;
+    uint32_t thr = 257;
+    if (FILTER) thr = (uint32_t)min(max(seed[min(qi, nq - 1)], 0), 256) + 1u;
     // four references per trip (32 SGPRs of s_load in flight); the inline-asm popcount chain keeps hipcc from unrolling a
     // runtime-trip-count loop by itself
     const int n4 = n & ~3;
     for (int j = 0; j < n4; j += 4) {
         const uint32_t *__restrict__ p4 = rp + (size_t)j * 8;
         const uint32_t d0 = hamming256(qv, p4), d1 = hamming256(qv, p4 + 8), d2 = hamming256(qv, p4 + 16), d3 = hamming256(qv, p4 + 24);
+        if (FILTER) {
+            const uint32_t m = min(min(min(d0, d1), d2), d3);   // v_min3_u32 + v_min_u32
+            if (__ballot(m < thr) == 0) continue;                 // wave-uniform
+        }
         const uint32_t k0 = (d0 << kKeyShift) | (uint32_t)j, k1 = (d1 << kKeyShift) | (uint32_t)(j + 1),
                        k2 = (d2 << kKeyShift) | (uint32_t)(j + 2), k3 = (d3 << kKeyShift) | (uint32_t)(j + 3);
-        second = med3u(best, k0, second); best = min(best, k0);
-        second = med3u(best, k1, second); best = min(best, k1);
-        second = med3u(best, k2, second); best = min(best, k2);
-        second = med3u(best, k3, second); best = min(best, k3);
+        if (FILTER) {
+            // lanes whose distances are all >= thr keep their state: a key at distance T + 1 or more must not enter (it would
+            // be harmless in this chunk but is not what the unfiltered scan of a later, emptier lane would report) -- keep it
+            // simple and exact: apply the rule only to distances below thr
+            const uint32_t e0 = d0 < thr ? k0 : kKeyNone, e1 = d1 < thr ? k1 : kKeyNone, e2 = d2 < thr ? k2 : kKeyNone,
+                           e3 = d3 < thr ? k3 : kKeyNone;
+            second = med3u(best, e0, second); best = min(best, e0);
+            second = med3u(best, e1, second); best = min(best, e1);
+            second = med3u(best, e2, second); best = min(best, e2);
+            second = med3u(best, e3, second); best = min(best, e3);
+            thr = min(thr, second >> kKeyShift);
+        } else {
+            second = med3u(best, k0, second); best = min(best, k0);
+            second = med3u(best, k1, second); best = min(best, k1);
+            second = med3u(best, k2, second); best = min(best, k2);
+            second = med3u(best, k3, second); best = min(best, k3);
+        }
     }
     for (int j = n4; j < n; j++) {
         const uint32_t d = hamming256(qv, rp + (size_t)j * 8);
-        const uint32_t key = (d << kKeyShift) | (uint32_t)j;
+        const uint32_t key = (!FILTER || d < thr) ? ((d << kKeyShift) | (uint32_t)j) : kKeyNone;
         second = med3u(best, key, second);
         best = min(best, key);
+        if (FILTER) thr = min(thr, second >> kKeyShift);
     }
     if (qi < nq) partial[(size_t)blockIdx.y * nqPad + qi] = make_uint2(best, second);
 }
@@ -102,15 +134,22 @@ __device__ __forceinline__ void knn2_fold(uint32_t &bd, int &bi, uint32_t &sd, u
     }
 }
 
+// Stage 1 (grid = query blocks of 64 x chunk groups): the group's chunks are cut into 4 consecutive runs folded by the 4
+// waves, the four runs are folded in order, and the group's (best_dist, best_idx, second_dist) goes to `groups`.  Stage 2
+// folds the groups of a query in order.  With one stage (nGroups == 1) the result goes straight to the outputs.
+struct KnnTriple { uint32_t bd; int bi; uint32_t sd; uint32_t pad; };
+
 __global__ __launch_bounds__(256) void knn2_merge_kernel(const uint2 *__restrict__ partial, int nChunks, int nqPad, int nq,
-                                                         int chunkLen, int idxBase, int *__restrict__ bestDist,
+                                                         int chunkLen, int idxBase, int chunksPerGroup,
+                                                         KnnTriple *__restrict__ groups, int *__restrict__ bestDist,
                                                          int *__restrict__ bestIdx, int *__restrict__ secondDist) {
     __shared__ uint32_t sBd[4][64], sSd[4][64];
     __shared__ int sBi[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int qi = blockIdx.x * 64 + lane;
-    const int per = (nChunks + 3) / 4;
-    const int cBeg = grp * per, cEnd = min(cBeg + per, nChunks);
+    const int g0 = blockIdx.y * chunksPerGroup, g1 = min(g0 + chunksPerGroup, nChunks);
+    const int per = (g1 - g0 + 3) / 4;
+    const int cBeg = g0 + grp * per, cEnd = min(cBeg + per, g1);
     uint32_t bd = 256, sd = 256;
     int bi = -1;
     if (qi < nq)
@@ -123,10 +162,32 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(const uint2 *__restrict
     if (grp == 0 && qi < nq) {
 #pragma unroll
         for (int gidx = 1; gidx < 4; gidx++) knn2_fold(bd, bi, sd, sBd[gidx][lane], sBi[gidx][lane], sSd[gidx][lane]);
-        bestDist[qi] = (int)bd;
-        bestIdx[qi] = bi;
-        secondDist[qi] = (int)sd;
+        if (groups) {
+            KnnTriple t;
+            t.bd = bd; t.bi = bi; t.sd = sd; t.pad = 0;
+            groups[(size_t)blockIdx.y * nqPad + qi] = t;
+        } else {
+            bestDist[qi] = (int)bd;
+            bestIdx[qi] = bi;
+            secondDist[qi] = (int)sd;
+        }
     }
+}
+
+__global__ __launch_bounds__(64) void knn2_merge_groups_kernel(const KnnTriple *__restrict__ groups, int nGroups, int nqPad, int nq,
+                                                               int *__restrict__ bestDist, int *__restrict__ bestIdx,
+                                                               int *__restrict__ secondDist) {
+    const int qi = blockIdx.x * 64 + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t bd = 256, sd = 256;
+    int bi = -1;
+    for (int g = 0; g < nGroups; g++) {
+        const KnnTriple t = groups[(size_t)g * nqPad + qi];
+        knn2_fold(bd, bi, sd, t.bd, t.bi, t.sd);
+    }
+    bestDist[qi] = (int)bd;
+    bestIdx[qi] = bi;
+    secondDist[qi] = (int)sd;
 }
 
 // candidate-list argmin: one query per lane, candidates scanned in list order

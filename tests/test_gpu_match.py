@@ -35,6 +35,33 @@ def test_knn2_matches_oracle(nq, nr):
         assert np.array_equal(g, r), name
 
 
+def test_knn2_filtered_scan_matches_oracle():
+    """Databases of 65536 references and more take the seeded scan (knn2_scan_kernel<true>: a pre-pass over the first 4096
+    references bounds the second-best distance, the selection then runs only where a reference can still matter).  Exact
+    against the oracle on random data with planted matches and ties, on a database sorted so that every reference improves
+    on the one before (the selection runs on every trip), and where the sample holds a single distinct descriptor."""
+    m = capi.ORBmatcher()
+    nr, nq = 70001, 300                                      # odd size: the tail loop of the last chunk runs too
+    db = synth.random_descriptors(nr, 900)
+    q = synth.planted_queries(db, nq, 901, planted_frac=0.3)
+    db[60000] = db[7]                                        # duplicate rows far apart: the first index wins, second == best
+    q[0] = db[7]
+    db[69999] = q[1]                                         # the exact match sits in the last chunk, after the sample
+    for case in range(3):
+        if case == 1:                                        # distances to q[2] fall steadily along the database
+            order = np.argsort(-np.unpackbits(db ^ q[2][None, :], axis=1).sum(1), kind="stable")
+            db = np.ascontiguousarray(db[order])
+        if case == 2:                                        # the sample is 4096 copies of one row: its second-best = its best
+            db = db.copy()
+            db[:4096] = db[5000]
+        got = _knn2(m, q, db)
+        ref = O.knn2(q, db)
+        for g, r, name in zip(got, ref, ("best_dist", "best_idx", "second_dist")):
+            assert np.array_equal(g, r), (case, name)
+    a = _knn2(m, q, db, idx_base=123456)
+    assert np.array_equal(a[1], ref[1] + 123456) and np.array_equal(a[0], ref[0]) and np.array_equal(a[2], ref[2])
+
+
 def test_knn2_empty_reference_and_index_base():
     m = capi.ORBmatcher()
     q = synth.random_descriptors(5, 1)
