@@ -45,7 +45,7 @@ def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
     threads = min(16, len(os.sched_getaffinity(0)))     # a 1-GPU box owns a 16-CPU share
     t, _ = O.time_extract(frames, NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, threads, reps=1)
     per_pass = max(t, 1e-3)
-    reps = int(max(1, min(200, budget_s / per_pass)))
+    reps = int(max(1, min(1000, budget_s / per_pass)))
     t, kps = O.time_extract(frames, NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, threads, reps=reps)
     n = len(frames) * reps
     return {"value": round(n / t, 2), "unit": "frames/s", "cores": threads, "kind": "port",
