@@ -206,6 +206,33 @@ def other_configs(local_rank, dev):
     out["search_by_bow_1500x2000_100_nodes"] = {"latency_ms_host_arrays_to_host_matches": round(float(np.median(lat)) * 1e3, 4),
                                                 "matches": int((mt >= 0).sum()),
                                                 "hamming_distances": int(sum((o1[k + 1] - o1[k]) * (o2[k + 1] - o2[k]) for k in range(nn)))}
+    # BASELINE.json configs[3] end to end: a KITTI-00-length sequence (4541 frames) in pinned host memory -> keypoints,
+    # descriptors and counts in pinned host memory (orbfe_extract_sequence: PCIe both ways, two chunks in flight)
+    nseq, capq = 4541, NFEATURES + 32
+    stride = (W + 63) // 64 * 64
+    uniq = synth.frame_sequence(8, W, H, first=700)
+    seq = torch.zeros((nseq, H, stride), dtype=torch.uint8).pin_memory()
+    sv = seq.numpy()
+    for i in range(nseq):
+        sv[i, :, :W] = uniq[i % 8]
+    skp = torch.zeros((nseq, capq, 7), dtype=torch.float32).pin_memory()
+    sde = torch.zeros((nseq, capq, 32), dtype=torch.uint8).pin_memory()
+    scn = torch.zeros(nseq, dtype=torch.int32).pin_memory()
+    exs = capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+    seq_call = lambda: exs.extract_sequence_host(seq.data_ptr(), nseq, W, H, stride, stride * H, skp.data_ptr(), sde.data_ptr(),
+                                                 scn.data_ptr(), capq, 256)
+    seq_call()
+    lat = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        seq_call()
+        lat.append(time.perf_counter() - t0)
+    tseq = float(np.median(lat))
+    out["sequence_4541_frames_pinned_host_to_pinned_host"] = {
+        "frames_per_s": round(nseq / tseq, 1), "seconds": round(tseq, 4), "chunk_frames": 256,
+        "host_to_device_GBps": round(nseq * stride * H / tseq / 1e9, 2), "device_to_host_GBps": round(nseq * capq * 60 / tseq / 1e9, 2),
+        "keypoints_per_frame": round(float(scn.float().mean()), 1)}
+    del seq, skp, sde, scn, exs
     # Fuse(KeyFrame*, vpMapPoints, th) selection (a-12): the same 1500 windows with th = 3 and the reprojection gate on the device
     sf = np.ones(8, np.float32)
     for i in range(1, 8):

@@ -92,6 +92,17 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
                         size_t frame_stride, orbfe_keypoint *dev_kps, uint8_t *dev_desc, int32_t *dev_counts, int cap,
                         int sync);
 int orbfe_synchronize(orbfe_extractor *e);
+/* The same operator over a whole sequence held in HOST memory (BASELINE.json config "batched offline extraction of 4541
+ * frames"; the reference's drivers feed one frame per TrackStereo call, Examples/Stereo/stereo_kitti.cc:66-108).  Frame f
+ * starts at host_imgs + f*frame_stride; stride and frame_stride must be multiples of 16.  The sequence is processed in chunks
+ * of chunk_frames (<= 0: 256) frames with two chunks in flight: the copy-in of the next chunk and the copy-out of the
+ * previous one run on their own streams under the kernels of the current chunk.  Outputs in host memory:
+ * host_kps[n_frames][cap], host_desc[n_frames][cap][32], host_counts[n_frames] (a frame with more than cap keypoints
+ * reports its full count and holds the first cap).  Synchronous.  Pinned host buffers (hipHostMalloc / hipHostRegister)
+ * let the copies run at PCIe rate and overlap; pageable buffers work but are staged by the runtime. */
+int orbfe_extract_sequence(orbfe_extractor *e, const uint8_t *host_imgs, int n_frames, int w, int h, int stride,
+                           size_t frame_stride, orbfe_keypoint *host_kps, uint8_t *host_desc, int32_t *host_counts, int cap,
+                           int chunk_frames);
 
 /* replaces the public member std::vector<cv::Mat> mvImagePyramid (include/ORBextractor.h:85; read by
  * src/Frame.cc:473,563,575,580).  Copies level `level` of frame `frame` of the LAST call into host memory laid out

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
     "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
-    "orbfe_search_area_ex", "orbfe_search_for_triangulation",
+    "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -84,6 +84,7 @@ def lib():
     L.orbfe_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, i32p]
     L.orbfe_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, C.c_int]
     L.orbfe_synchronize.argtypes = [vp]
+    L.orbfe_extract_sequence.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, C.c_int]
     L.orbfe_pyramid_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, i32p, i32p]
     L.orbfe_debug_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbfe_hamming.argtypes = [vp, vp]
@@ -205,6 +206,11 @@ class ORBextractor:
         """Batched extraction on frames resident in HBM; pointers are raw device addresses (e.g. tensor.data_ptr())."""
         check(self._L.orbfe_extract_batch(self._h, vp(dev_imgs_ptr), n_frames, w, h, stride, frame_stride, vp(dev_kps_ptr),
                                           vp(dev_desc_ptr), vp(dev_counts_ptr), cap, 1 if sync else 0))
+
+    def extract_sequence_host(self, imgs_ptr: int, n_frames, w, h, stride, frame_stride, kps_ptr, desc_ptr, counts_ptr, cap, chunk=0):
+        """orbfe_extract_sequence: host frames in, host keypoints / descriptors / counts out (pointers to host memory)."""
+        check(self._L.orbfe_extract_sequence(self._h, vp(imgs_ptr), n_frames, w, h, stride, frame_stride, vp(kps_ptr), vp(desc_ptr),
+                                             vp(counts_ptr), cap, chunk))
 
     def synchronize(self):
         check(self._L.orbfe_synchronize(self._h))

@@ -122,6 +122,10 @@ struct orbfe_extractor {
     int2 *pCellTab = nullptr;
     size_t countersBytes = 0;
     PinBuf hCand, hLevelCount, hCellTab, hSel, hSelCount;
+    // host-sequence path (orbfe_extract_sequence): two chunks in flight
+    DevBuf seqIn[2], seqKps[2], seqDesc[2], seqCnt[2];
+    hipStream_t seqInStream = nullptr, seqOutStream = nullptr;
+    hipEvent_t seqEvIn[2] = {nullptr, nullptr}, seqEvComp[2] = {nullptr, nullptr}, seqEvOut[2] = {nullptr, nullptr};
     // single-image path
     DevBuf dImg, dKps, dDesc, dCounts;
     PinBuf hImg, hKps, hDesc, hCounts;
@@ -818,8 +822,17 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
             if (ev) (void)hipEventDestroy(ev);
         if (p.counts) (void)hipHostFree(p.counts);
     }
+    for (hipStream_t st : {e->seqInStream, e->seqOutStream})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (int b = 0; b < 2; b++)
+        for (hipEvent_t ev : {e->seqEvIn[b], e->seqEvComp[b], e->seqEvOut[b]})
+            if (ev) (void)hipEventDestroy(ev);
     for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dDescMask, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
-                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts})
+                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->seqIn[0], &e->seqIn[1], &e->seqKps[0], &e->seqKps[1],
+                      &e->seqDesc[0], &e->seqDesc[1], &e->seqCnt[0], &e->seqCnt[1]})
         b->release();
     for (PinBuf *b : {&e->hImg, &e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
         b->release();
@@ -916,6 +929,67 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
     e->lastCall = {dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap};
     e->batchesInFlight++;
     return sync ? orbfe_synchronize(e) : ORBFE_OK;
+}
+
+int orbfe_extract_sequence(orbfe_extractor *e, const uint8_t *host_imgs, int n_frames, int w, int h, int stride,
+                           size_t frame_stride, orbfe_keypoint *host_kps, uint8_t *host_desc, int32_t *host_counts, int cap,
+                           int chunk_frames) {
+    if (!e || !host_imgs || !host_kps || !host_desc || !host_counts) return fail(ORBFE_ERR_ARG, "null argument");
+    if (n_frames < 1 || w < 1 || h < 1 || cap < 1) return fail(ORBFE_ERR_ARG, "bad size");
+    if (stride < w || (stride & 15) || (frame_stride & 15) || frame_stride < (size_t)stride * h)
+        return fail(ORBFE_ERR_ARG, "stride and frame_stride must be multiples of 16 (stride >= w)");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->batchesInFlight) {   // asynchronous batches of the caller come first, with their own status handling
+        const int rc0 = orbfe_synchronize(e);
+        if (rc0) return rc0;
+    }
+    const int chunk = std::min(n_frames, chunk_frames > 0 ? chunk_frames : 256);
+    if (!e->seqInStream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->seqInStream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&e->seqOutStream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(hipEventCreateWithFlags(&e->seqEvIn[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->seqEvComp[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->seqEvOut[b], hipEventDisableTiming));
+        }
+    }
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(e->seqIn[b].ensure((size_t)chunk * frame_stride + 256));
+        HIPCHK(e->seqKps[b].ensure((size_t)chunk * cap * sizeof(orbfe_keypoint)));
+        HIPCHK(e->seqDesc[b].ensure((size_t)chunk * cap * 32));
+        HIPCHK(e->seqCnt[b].ensure((size_t)chunk * sizeof(int32_t)));
+    }
+    const int nChunks = (n_frames + chunk - 1) / chunk;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // chunk k: copy in on seqInStream, extract on the handle's stream, copy out on seqOutStream; buffers alternate, so the
+        // copy-in of chunk k+1 and the copy-out of chunk k-1 run under the kernels of chunk k
+        for (int k = 0; k < nChunks; k++) {
+            const int b = k & 1, f0 = k * chunk, F = std::min(chunk, n_frames - f0);
+            if (k >= 2) HIPCHK(hipStreamWaitEvent(e->seqInStream, e->seqEvComp[b], 0));    // input buffer b has been consumed
+            HIPCHK(hipMemcpyAsync(e->seqIn[b].p, host_imgs + (size_t)f0 * frame_stride, (size_t)F * frame_stride, hipMemcpyHostToDevice,
+                                  e->seqInStream));
+            HIPCHK(hipEventRecord(e->seqEvIn[b], e->seqInStream));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->seqEvIn[b], 0));
+            if (k >= 2) HIPCHK(hipStreamWaitEvent(e->stream, e->seqEvOut[b], 0));         // output buffers b have been copied out
+            const int rc = run_batch(e, (const uint8_t *)e->seqIn[b].p, F, w, h, stride, frame_stride, (orbfe_keypoint *)e->seqKps[b].p,
+                                     (uint8_t *)e->seqDesc[b].p, (int32_t *)e->seqCnt[b].p, cap);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->seqEvComp[b], e->stream));
+            HIPCHK(hipStreamWaitEvent(e->seqOutStream, e->seqEvComp[b], 0));
+            HIPCHK(hipMemcpyAsync(host_kps + (size_t)f0 * cap, e->seqKps[b].p, (size_t)F * cap * sizeof(orbfe_keypoint),
+                                  hipMemcpyDeviceToHost, e->seqOutStream));
+            HIPCHK(hipMemcpyAsync(host_desc + (size_t)f0 * cap * 32, e->seqDesc[b].p, (size_t)F * cap * 32, hipMemcpyDeviceToHost,
+                                  e->seqOutStream));
+            HIPCHK(hipMemcpyAsync(host_counts + f0, e->seqCnt[b].p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost, e->seqOutStream));
+            HIPCHK(hipEventRecord(e->seqEvOut[b], e->seqOutStream));
+        }
+        HIPCHK(hipStreamSynchronize(e->seqOutStream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const int rc = fetch_status(e);
+        e->batchesInFlight = 0;
+        if (rc != kRerunBigList) return rc;   // otherwise the whole sequence once more with the large FAST survivor list
+    }
+    return fail(ORBFE_ERR_CAPACITY, "FAST survivor list overflowed its upper bound (internal error)");
 }
 
 int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stride, orbfe_keypoint *kps, int cap,

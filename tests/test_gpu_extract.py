@@ -306,3 +306,38 @@ def test_two_extractors_from_two_host_threads():
     for t in th:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_extract_sequence_host_to_host(pinned):
+    """orbfe_extract_sequence: a sequence in host memory, chunks of 8 with two in flight and a ragged last chunk; every
+    frame bit-exact against the oracle.  Second sequence (the configuration of the dense-noise test above): uniform-noise
+    frames between ordinary ones make the FAST survivor list overflow, and the whole sequence is run again with the
+    large-list kernel variant inside the call."""
+    torch = pytest.importorskip("torch")
+    for (w, h, n, cap, chunk, params, noise) in [(640, 480, 21, 1100, 8, (1000, 1.2, 8, 20, 7), ()),
+                                                 (1491, 344, 5, 200, 2, (100, 2.0, 3, 35, 2), (1, 3))]:
+        stride = (w + 63) // 64 * 64
+        t = torch.zeros((n, h, stride), dtype=torch.uint8)
+        kps = torch.zeros((n, cap, 7), dtype=torch.float32)
+        desc = torch.zeros((n, cap, 32), dtype=torch.uint8)
+        cnt = torch.zeros(n, dtype=torch.int32)
+        if pinned:
+            t, kps, desc, cnt = t.pin_memory(), kps.pin_memory(), desc.pin_memory(), cnt.pin_memory()
+        host = t.numpy()
+        for f in range(n):
+            host[f, :, :w] = (np.random.default_rng(9176 + f).integers(0, 256, (h, w)).astype(np.uint8) if f in noise
+                              else synth.textured_image(w, h, synth.BASE_SEED + 400 + f))
+        o = O.OracleExtractor(*params)
+        g = capi.ORBextractor(*params)
+        g.extract_sequence_host(t.data_ptr(), n, w, h, stride, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, chunk=chunk)
+        kh = kps.numpy().view(np.uint8).reshape(n, cap, 28)
+        for f in range(n):
+            kr, dr = o.extract(np.ascontiguousarray(host[f, :, :w]))
+            if f in noise:
+                assert sum(len(o.candidates(l)) for l in range(params[2])) > 40000
+            assert int(cnt[f]) == len(kr), (w, f)
+            assert np.array_equal(kh[f, :len(kr)].copy().view(capi.KP_DTYPE).reshape(-1), kr), (w, f)
+            assert np.array_equal(desc.numpy()[f, :len(kr)], dr), (w, f)
+    with pytest.raises(capi.OrbfeError):
+        g.extract_sequence_host(t.data_ptr(), n, w, h, stride + 4, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap)
