@@ -73,6 +73,16 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(
 __device__ __forceinline__ u16x2 pkmax(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u16x2 pkmin(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ u16x2 pksubsat(u16x2 a, u16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
+// per 16-bit lane: s where s > lim, else 0 -- saturating subtract, min with 1, multiply.  Spelled out: written with the
+// elementwise builtins the compiler rewrites it into 16-bit compares and selects per half (11 instructions per pixel pair
+// instead of 3).
+__device__ __forceinline__ uint32_t pk_keep_above(u16x2 s, u16x2 lim, u16x2 one) {
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3\n\tv_pk_mul_lo_u16 %0, %1, %0"
+        : "=&v"(r)
+        : "v"(__builtin_bit_cast(uint32_t, s)), "v"(__builtin_bit_cast(uint32_t, lim)), "v"(__builtin_bit_cast(uint32_t, one)));
+    return r;
+}
 
 // even pixels (bytes 0,2) / odd pixels (bytes 1,3) of a 4-pixel byte window as two 16-bit lanes
 __device__ __forceinline__ u16x2 pair_even(uint32_t w) { return as_pk(w & 0x00FF00FFu); }
@@ -311,24 +321,21 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
             cur.ho = pkmax(lo, ro);
             cur.me = pkmax(cur.he, se);
             cur.mo = pkmax(cur.ho, so);
-            // ---- output row o = c-1 (`prev`): rows o-1 = pp (masked on the cell's first row), o+1 = cur.
-            //      For c = 0 there is no row yet: prev is all zero, so nothing is kept.
-            const uint32_t topOK = c > 1 ? 0xFFFFFFFFu : 0u;
-            u16x2 ne = pkmax(prev.he, as_pk(as_u32(ppMe) & topOK)), no = pkmax(prev.ho, as_pk(as_u32(ppMo) & topOK));
+            // ---- output row o = c-1 (`prev`): rows o-1 = pp, o+1 = cur.  The score rows start out as zeros, so for c = 0
+            //      (no row yet: prev is all zero, nothing is kept) and c = 1 (the cell's first row: pp is still the zero row,
+            //      as NMS must not look above the cell) no masking is needed.
+            u16x2 ne = pkmax(prev.he, ppMe), no = pkmax(prev.ho, ppMo);
             ne = pkmax(ne, cur.me);
             no = pkmax(no, cur.mo);
             // keep S iff S > max(neighbours, minTh)
-            const u16x2 ke = pkmin(pksubsat(prev.se, pkmax(ne, thPair)), one), ko = pkmin(pksubsat(prev.so, pkmax(no, thPair)), one);
-            const uint32_t pe = as_u32(prev.se * ke), po = as_u32(prev.so * ko);
+            const uint32_t pe = pk_keep_above(prev.se, pkmax(ne, thPair), one), po = pk_keep_above(prev.so, pkmax(no, thPair), one);
             emit_row((pe | (po << 8)) & ownMask, c - 1);
         }
     }
     {
-        // ---- last row o = dh-1 (`cur`): row above = prev (masked if the cell row has a single row), nothing below
-        const uint32_t topOK = dh > 1 ? 0xFFFFFFFFu : 0u;
-        const u16x2 ne = pkmax(cur.he, as_pk(as_u32(prev.me) & topOK)), no = pkmax(cur.ho, as_pk(as_u32(prev.mo) & topOK));
-        const u16x2 ke = pkmin(pksubsat(cur.se, pkmax(ne, thPair)), one), ko = pkmin(pksubsat(cur.so, pkmax(no, thPair)), one);
-        const uint32_t pe = as_u32(cur.se * ke), po = as_u32(cur.so * ko);
+        // ---- last row o = dh-1 (`cur`): row above = prev (the zero row if the cell row has a single row), nothing below
+        const u16x2 ne = pkmax(cur.he, prev.me), no = pkmax(cur.ho, prev.mo);
+        const uint32_t pe = pk_keep_above(cur.se, pkmax(ne, thPair), one), po = pk_keep_above(cur.so, pkmax(no, thPair), one);
         emit_row((pe | (po << 8)) & ownMask, dh - 1);
     }
 
