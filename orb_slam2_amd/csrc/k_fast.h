@@ -261,11 +261,13 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
     // a lane whose dword holds a kept score appends one record (kept scores, recTag | row << 18); row-major order
     // Two horizontally adjacent pixels can both be kept only across a cell edge (NMS does not look over it); a lane with
     // kept scores on both sides of an edge writes two records, so that a record holds one cell's scores: at most two.
+    const unsigned long long edgeLanes = __ballot(sameCell != 0xFFFFFFFFu);   // lanes whose dword is cut by a cell edge
     auto emit_row = [&](uint32_t Pd, int o) {
         const unsigned long long Bm = __ballot(Pd != 0);
         if (Bm != 0) {   // wave-uniform
             const uint32_t PdA = Pd & sameCell, PdB = Pd & ~sameCell;
-            const unsigned long long Bs = __ballot(PdA != 0 && PdB != 0);
+            unsigned long long Bs = 0;
+            if (Bm & edgeLanes) Bs = __ballot(PdA != 0 && PdB != 0);   // scalar test: only an edge lane can hold two cells' scores
             int pos = listCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(Bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bm, 0));
             if (Bs != 0) {   // wave-uniform, rare
                 pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(Bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bs, 0));
