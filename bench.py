@@ -389,6 +389,15 @@ def main():
                         "--handles > 1 the other handle's kernels run concurrently and inflate it); stage_ms_per_step "
                         "comes from 5 extra un-timed steps with events around every stage",
                 "stage_ms_per_step": stages}
+    # every dense stage against HBM (algorithmic bytes per frame, each datum moved once), from the
+    # un-timed per-stage pass; the descriptor stage by the unique bytes it gathers (749 B disc + <= 1369 B window + 60 B out)
+    spf = sum(p["frames"] for p in stage_profs) / 5
+    kp_pf = sum(p["keypoints"] for p in stage_profs) / max(sum(p["frames"] for p in stage_profs), 1)
+    stage_bytes = {"pyramid": 2385248, "fast": LEVEL_PIXELS + 8 * cand_per_frame, "blur": 2 * LEVEL_PIXELS,
+                   "describe": (749 + 1369 + 60) * kp_pf, "quadtree": 8 * cand_per_frame}
+    roofline["stage_hbm"] = {k: {"algorithmic_GBps": round(stage_bytes[k] * spf / (stages[k] * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBps": round(stage_bytes[k] * spf / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                             for k in stage_bytes if stages.get(k, 0) > 0}
 
     # ---- Hamming kNN-2: 2000 queries vs a 1M database sharded over the ranks, RCCL gather of per-shard results
     hamming = None
