@@ -4,8 +4,12 @@
 // computeDescriptors (:108-147, 1034-1041) and the output assembly of operator() (:1072-1104: pt *= scale for level > 0,
 // level-major concatenation).
 //
-// One wavefront handles 16 consecutive keypoints of a frame, in three phases, so that the per-keypoint scalar math
-// (fastAtan2, cos, sin) is done ONCE for 16 keypoints with one keypoint per lane instead of 64 times redundantly:
+// One wavefront handles kDescKpPerWave (8) consecutive keypoints of a frame, in three phases, so that the per-keypoint
+// scalar math (fastAtan2, cos, sin) is done ONCE for the 8 keypoints with one keypoint per lane instead of 64 times
+// redundantly.  8 rather than 16 per wave: the keypoints resident on an XCD at one time then belong to 3 frames instead of
+// 6 and more of the patches stay in its 4-MiB L2 (measured TCC misses per 512-frame launch: 29.3 M at 16 keypoints per
+// wave, 12.2 M at 4); 8 % faster than 16 although the per-wave fixed work is spread over half as many keypoints, and
+// as fast as 4, where that fixed work eats the gain.
 //   1. moments, one keypoint at a time: the 31 disc rows of the UN-blurred level are fetched as 31 x 9 aligned dwords
 //      (5 per lane); per dword two v_dot4_u32_u8 against a mask / weight pair from an LDS table indexed by the patch's
 //      alignment (cx-15)&3 give sum(I) and sum((u+18) I) over the bytes inside the disc; m01 += v*sum(I); a DPP
@@ -105,13 +109,15 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double *s, double *c) {
     *c = ((q + 1) & 2) ? -c0 : c0;
 }
 
-constexpr int kDescKpPerWave = 16;
+constexpr int kDescKpPerWave = 8;
 constexpr int kDescKpPerGroup = 4 * kDescKpPerWave;
 constexpr int kDescWinR = 18;                              // rotated taps reach at most round(hypot(13,13)) = 18 pixels
 constexpr int kDescWinRows = 2 * kDescWinR + 1;            // 37
 constexpr int kDescWinDw = 12;                             // LDS row: 3 x 16 bytes (37 bytes + up to 3 of alignment slack used)
 constexpr int kDescWinItems = kDescWinRows * 3;            // 16-byte loads of the blurred window (111: two per lane)
 constexpr int kDescMomentItems = 31 * 3;                   // 16-byte loads of the 31 x 36 moment window (93: two per lane)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     }
     __syncthreads();
 
-    // ---- the wave's 16 keypoints, one per lane (lanes >= 16 mirror lanes 0..15): level, slot, geometry
+    // ---- the wave's keypoints, one per lane (the other lanes mirror them): level, slot, geometry
     const int iBase = grp * kDescKpPerGroup + wv * kDescKpPerWave;
-    const int i = iBase + (lane & 15);   // keypoint index inside the frame, level-major
+    const int i = iBase + (lane & (kDescKpPerWave - 1));   // keypoint index inside the frame, level-major
     int lvl = -1, j = i, total = 0, selOff = 0, pitchV = 0, bpV = 0, wV = 2 * kEdge + 1, hV = 2 * kEdge + 1;
     unsigned long long imgV = 0, blurV = 0;
     float scaleV = 1.f, patchV = 0.f;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     }
     if (iBase == 0 && lane == 0) a.counts[f] = total;
     const bool valid = lvl >= 0 && i < a.cap;
-    const int nValid = __popcll(__ballot(valid && lane < kDescKpPerWave));   // valid keypoints are a prefix of the 16
+    const int nValid = __popcll(__ballot(valid && lane < kDescKpPerWave));   // valid keypoints are a prefix
     if (nValid == 0) return;
     SelKp kp = {};
     if (valid) kp = a.sel[(size_t)f * a.g.selFrameCap + selOff + j];
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float ca = __builtin_bit_cast(float, rl(caI, k)), sb = __builtin_bit_cast(float, rl(sbI, k));
+            const f32x2 sc = {sb, ca}, cs = {ca, -sb};   // py * (-sb) = -(py * sb) exactly
             const int cx = rl(cxV, k);
             const int origin = kDescWinR * (4 * kDescWinDw) + cx - ((cx - kDescWinR) & ~3);   // byte of the keypoint in the window
             const int originM = origin - 0x4B400000;                                          // minus the bits of 1.5*2^23
@@ -351,11 +358,16 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
                 // cvRound by the 1.5*2^23 trick: for |x| < 2^22 the float add rounds x to the nearest-even integer and leaves
                 // it in the low mantissa bits; the tap's byte address r*40 + c + origin then takes one v_mad_i32_i16
                 // on the low halves (bits 0..15 of the sum are r as int16) plus one add
-                const float kMagic = 12582912.f;
-                const int r0 = __builtin_bit_cast(int, __fadd_rn(__fadd_rn(__fmul_rn(px0[t], sb), __fmul_rn(py0[t], ca)), kMagic));
-                const int c0 = __builtin_bit_cast(int, __fadd_rn(__fsub_rn(__fmul_rn(px0[t], ca), __fmul_rn(py0[t], sb)), kMagic));
-                const int r1 = __builtin_bit_cast(int, __fadd_rn(__fadd_rn(__fmul_rn(px1[t], sb), __fmul_rn(py1[t], ca)), kMagic));
-                const int c1 = __builtin_bit_cast(int, __fadd_rn(__fsub_rn(__fmul_rn(px1[t], ca), __fmul_rn(py1[t], sb)), kMagic));
+                // two floats per instruction (v_pk_mul_f32 / v_pk_add_f32, each half individually rounded): (row, col) of a tap
+                // = (px, px) * (sb, ca) + (py, py) * (ca, -sb) as two products and one sum, then the rounding constant
+                const f32x2 kMagic = {12582912.f, 12582912.f};
+                const f32x2 a0 = f32x2{px0[t], px0[t]} * sc, b0 = f32x2{py0[t], py0[t]} * cs;
+                const f32x2 a1 = f32x2{px1[t], px1[t]} * sc, b1 = f32x2{py1[t], py1[t]} * cs;
+                const f32x2 rc0 = (a0 + b0) + kMagic, rc1 = (a1 + b1) + kMagic;
+                // (elements copied to scalars first: __builtin_bit_cast applied to a vector element reads element 0)
+                const float r0f = rc0.x, c0f = rc0.y, r1f = rc1.x, c1f = rc1.y;
+                const int r0 = __builtin_bit_cast(int, r0f), c0 = __builtin_bit_cast(int, c0f);
+                const int r1 = __builtin_bit_cast(int, r1f), c1 = __builtin_bit_cast(int, c1f);
                 const int t0 = win[mad_i16(r0, 4 * kDescWinDw, c0 + originM)];
                 const int t1 = win[mad_i16(r1, 4 * kDescWinDw, c1 + originM)];
                 nib |= (uint32_t)(t0 < t1) << t;
