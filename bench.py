@@ -389,6 +389,13 @@ def main():
                         "--handles > 1 the other handle's kernels run concurrently and inflate it); stage_ms_per_step "
                         "comes from 5 extra un-timed steps with events around every stage",
                 "stage_ms_per_step": stages}
+    # the resource FAST is actually bound by: VALU issue slots.  SQ_INSTS_VALU of this kernel is 646.6 M wave instructions per
+    # 512-frame launch of this workload (profiles/r1f_pmc_summary.txt; the count depends on the frames, not on the run), a
+    # packed-integer instruction occupies a SIMD for 4.15 cycles (profiles/r1_valu_rates_ubench.txt), 1024 SIMDs at 2.4 GHz.
+    valu_instr = 646.6e6 / 512 * frames_per_launch
+    roofline["valu_issue"] = {"wave_instructions_per_launch": int(valu_instr), "cycles_per_instruction": 4.15,
+                              "frac": round(valu_instr * 4.15 / (1024 * 2.4e9 * fast_ms * 1e-3), 4) if fast_ms > 0 else None,
+                              "note": "instruction count from the PMC pass in profiles/, duration live; 2.4 GHz nominal clock"}
     # every dense stage against HBM (algorithmic bytes per frame, each datum moved once), from the
     # un-timed per-stage pass; the descriptor stage by the unique bytes it gathers (749 B disc + <= 1369 B window + 60 B out)
     spf = sum(p["frames"] for p in stage_profs) / 5
@@ -451,6 +458,20 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(uniq)
+        if hamming is not None:
+            # the matcher's CPU side: the reference's SWAR popcount loop (src/ORBmatcher.cc:1654-1660) and a
+            # __builtin_popcount variant of the same best / second-best scan, one block of queries per host thread
+            sys.path.insert(0, str(ROOT / "tests"))
+            import oracle_lib as O
+            threads = min(16, len(os.sched_getaffinity(0)))
+            db_host = db.cpu().numpy()
+            ns = len(db_host)       # 2e9 pairs: a few tenths of a second on the GPU box's 16 host threads
+            t_swar = O.time_knn2(q_host, db_host[:ns], threads, swar=True)
+            t_pop = O.time_knn2(q_host, db_host, threads, swar=False)
+            hamming["cpu_baseline"] = {"value": round(NQ * ns / t_swar, 1), "unit": "pair distances/s", "cores": threads, "kind": "port",
+                                       "sample": f"{NQ} queries x {ns} descriptors with the reference's SWAR DescriptorDistance in {t_swar:.2f} s",
+                                       "popcnt_variant": round(NQ * len(db_host) / t_pop, 1),
+                                       "popcnt_sample": f"{NQ} x {len(db_host)} with __builtin_popcount in {t_pop:.2f} s"}
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
