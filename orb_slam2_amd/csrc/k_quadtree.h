@@ -447,12 +447,20 @@ __device__ __forceinline__ void quadtree_run(const QuadtreeArgs &a, QtShared<MAX
 #endif
 }
 
+// 4 workgroups per CU (128 registers, 7 of them spilled) instead of the 3 that the natural 145 registers allow: the trees
+// are latency-bound (a chain of barrier-separated LDS steps), so residency is what counts: 0.213 -> 0.176 ms per 512
+// frames; a 5th (96 registers, 41 spilled) is slower again.
 template <int MAXN>
-__global__ __launch_bounds__(256) void quadtree_kernel(QuadtreeArgs a) {
+__global__ __launch_bounds__(256, 4) void quadtree_kernel(QuadtreeArgs a) {
     extern __shared__ __align__(16) uint8_t qt_lds_raw[];
     QtShared<MAXN> &S = *reinterpret_cast<QtShared<MAXN> *>(qt_lds_raw);
     const int tid = threadIdx.x;
-    const int lvl = blockIdx.x, f = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest).  With (level, frame) = (x, y) and 8 levels
+    // every level-0 tree -- the longest -- would land on XCD 0 and every level-7 tree on XCD 7.  The launch index is
+    // therefore read level-major: all level-0 trees first, spread over the XCDs, then level 1, ... (longest first, which
+    // also packs the tail).
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, nF = gridDim.y;
+    const int lvl = id / nF, f = id - lvl * nF;
     const LevelGeom &L = a.g.lv[lvl];
     int n = a.levelCount[f * kMaxLevels + lvl];
     if (n > L.candCap) {
