@@ -126,6 +126,13 @@ def check(rc):
         raise OrbfeError(rc, lib().orbfe_last_error().decode())
 
 
+def _check_csr(off, idx, what):
+    """The C-ABI takes node_off[n_nodes] as the length of node_idx (it sees only pointers): a binding that knows the array
+    lengths must refuse an offset array that promises more entries than the index array holds."""
+    if len(off) < 1 or int(off[-1]) != len(idx):
+        raise OrbfeError(-1, f"{what}: node offsets end at {int(off[-1]) if len(off) else None}, index array holds {len(idx)}")
+
+
 def _np_ptr(a):
     return a.ctypes.data_as(vp)
 
@@ -324,6 +331,8 @@ class ORBmatcher:
         v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
         b2 = None if blocked2 is None else np.ascontiguousarray(blocked2, np.uint8)
         o1, i1, o2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
+        _check_csr(o1, i1, "side 1")
+        _check_csr(o2, i2, "side 2")
         match1 = np.zeros(max(len(d1), 1), np.int32)
         check(self._L.orbfe_search_by_bow(self._h, _np_ptr(d1), None if v1 is None else _np_ptr(v1), len(d1), _np_ptr(d2),
                                           None if b2 is None else _np_ptr(b2), len(d2), _np_ptr(o1), _np_ptr(i1), _np_ptr(o2),
@@ -342,6 +351,8 @@ class ORBmatcher:
         f1, i1, f2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
         F = np.ascontiguousarray(F12, np.float32).reshape(9)
         sf, s2 = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+        _check_csr(f1, i1, "side 1")
+        _check_csr(f2, i2, "side 2")
         match1 = np.zeros(max(len(d1), 1), np.int32)
         check(self._L.orbfe_search_for_triangulation(self._h, _np_ptr(d1), _np_ptr(h1), _np_ptr(u1), _np_ptr(x1), len(d1), _np_ptr(d2),
                                                      _np_ptr(h2), _np_ptr(u2), _np_ptr(x2), _np_ptr(o2), len(d2), _np_ptr(f1),

@@ -13,7 +13,8 @@
 // Register-sliding design, no LDS and no barriers.  One wavefront owns a vertical strip of 62 dword columns (248 px)
 // x kBlurRows rows of one level of one frame and walks down it:
 //   * per row every lane loads ONE aligned dword (a fully coalesced 256-B row segment) and splits it into the pixel
-//     pairs (p0,p2), (p1,p3) in 16-bit lanes; lanes 0 and 63 are the halo columns;
+//     pairs (p0,p2), (p1,p3) in 16-bit lanes; lanes 0 and 63 are the halo columns, except at the image's left and right
+//     edge, where the edge lane reflects its own data and writes too (host-built strip list: BlurTile);
 //   * column pass: the last seven rows stay in registers in pair form (the loop is unrolled by 7 so the window rotates
 //     by renaming); the symmetric kernel needs 3 v_pk_add_u16 + 1 v_pk_mul_lo_u16 + 3 v_pk_mad_u16 per pixel pair;
 //   * row pass: the left/right neighbour lanes' V pairs arrive by DPP wave shifts; the 7 taps of the dword's four pixels
@@ -30,7 +31,7 @@ constexpr int kBlurStripDw = 62;       // output dword columns per wave (lanes 1
 constexpr int kBlurRows = 64;          // output rows per wave; kBlurRows + 6 must be a multiple of 7
 static_assert((kBlurRows + 6) % 7 == 0, "row loop is unrolled by 7");
 
-struct BlurTile { uint16_t level, tx, ty, pad; };
+struct BlurTile { uint16_t level; int16_t xdw0; uint16_t ty; uint8_t lane0, lane1; };   // xdw0: dword column of lane 0; lanes lane0..lane1 write
 
 __device__ __forceinline__ int refl101(int p, int n) {
     p = p < 0 ? -p : p;
@@ -64,9 +65,9 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
     const uint8_t *img = level_ptr(s, g, f, t.level, &pitch);
     uint8_t *dst = s.blur + (size_t)f * g.blurFrameBytes + L.blurOff;
     const int w = L.w, h = L.h;
-    const int x0 = 4 * (t.tx * kBlurStripDw + lane - 1);
+    const int x0 = 4 * (t.xdw0 + lane);
     const int y0 = t.ty * kBlurRows;
-    const bool writer = lane >= 1 && lane <= kBlurStripDw && x0 < w;
+    const bool writer = lane >= t.lane0 && lane <= t.lane1 && x0 < w;
 
     // Horizontal BORDER_REFLECT_101 on the column sums V, without branches.  VE = (V0,V2), VO = (V1,V3) are the lane's
     // pairs, VEL/VOL the left neighbour's (V-4,V-2), (V-3,V-1), VER/VOR the right neighbour's (V4,V6), (V5,V7).

@@ -377,11 +377,22 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
             if (L.h > 65535) return fail(ORBFE_ERR_UNSUPPORTED, "image larger than 65535 pixels on a side");
             e->rszRows[l] = rows;
         }
+        // blur strips: a lane column is one dword; interior strips write lanes 1..62 (lanes 0 and 63 are halo columns), the
+        // strip at the left image edge also writes lane 0 and the one at the right edge may end in lane 63 (reflection
+        // needs no neighbour there): 1241 px = 311 dwords = 63 + 3 x 62 + 63 take 5 strips, not 6
+        const int wd = (L.w + 3) / 4;
         for (int ty = 0; ty * kBlurRows < L.h; ty++)
-            for (int tx = 0; tx * kBlurStripDw * 4 < L.w; tx++) {
+            for (int d0 = 0; d0 < wd;) {
                 BlurTile t;
-                t.level = (uint16_t)l; t.tx = (uint16_t)tx; t.ty = (uint16_t)ty; t.pad = 0;
+                t.level = (uint16_t)l; t.ty = (uint16_t)ty;
+                const int first = d0 == 0 ? 0 : 1;          // lane of dword column d0
+                const int room = 64 - first;                // lanes first..63
+                const int left = wd - d0;
+                const int n = left <= room ? left : room - 1;   // not the last strip: lane 63 stays a halo column
+                t.xdw0 = (int16_t)(d0 - first);
+                t.lane0 = (uint8_t)first; t.lane1 = (uint8_t)(first + n - 1);
                 e->hBlurTiles.push_back(t);
+                d0 += n;
             }
     }
     g.totalCells = cellBase;
