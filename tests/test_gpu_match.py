@@ -62,6 +62,25 @@ def test_knn2_filtered_scan_matches_oracle():
     assert np.array_equal(a[1], ref[1] + 123456) and np.array_equal(a[0], ref[0]) and np.array_equal(a[2], ref[2])
 
 
+def test_knn2_many_queries_fewer_main_chunks_than_sample_chunks():
+    """70 000 queries make the main scan use fewer chunks (29) than the pre-pass (32 chunks of 64 references): the per-chunk
+    buffers are sized for the larger of the two.  No oracle at this size (2.8e9 pairs): every query block must get what
+    the same queries get when they are matched on their own (a call that takes hundreds of chunks), and the first 300
+    are checked against the oracle."""
+    m = capi.ORBmatcher()
+    nr, nq = 40000, 70000
+    db = synth.random_descriptors(nr, 910)
+    q = synth.planted_queries(db, nq, 911, planted_frac=0.2)
+    got = _knn2(m, q, db)
+    for lo in (0, 33333, nq - 1500):
+        part = _knn2(m, q[lo:lo + 1500], db)
+        for g, r, name in zip(got, part, ("best_dist", "best_idx", "second_dist")):
+            assert np.array_equal(g[lo:lo + 1500], r), (lo, name)
+    ref = O.knn2(q[:300], db)
+    for g, r, name in zip(got, ref, ("best_dist", "best_idx", "second_dist")):
+        assert np.array_equal(g[:300], r), name
+
+
 def test_knn2_empty_reference_and_index_base():
     m = capi.ORBmatcher()
     q = synth.random_descriptors(5, 1)
