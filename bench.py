@@ -294,11 +294,20 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # ORBFE_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks: the ranks share the
+    # GPUs round-robin and the (tiny) collectives go through host tensors.  The driver's runs use the default, RCCL.
+    backend = os.environ.get("ORBFE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective operands live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -362,7 +371,7 @@ def main():
             "frames": sum(p["frames"] for p in profs), "candidates": sum(p["candidates"] for p in profs),
             "keypoints": sum(p["keypoints"] for p in profs)}
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_frames = B * args.steps * world
@@ -416,17 +425,22 @@ def main():
         q = torch.from_numpy(q_host).to(dev)
         res = torch.zeros((3, NQ), dtype=torch.int32, device=dev)
         m = capi.ORBmatcher(device=local_rank)
-        gathered = torch.zeros((world, 3, NQ), dtype=torch.int32, device=dev) if world > 1 else None
+        gathered = torch.zeros((world * 3, NQ), dtype=torch.int32, device=cdev) if world > 1 else None
 
         def hstep():
             if world > 1:
-                dist.broadcast(q, src=0)
+                if cdev is dev:
+                    dist.broadcast(q, src=0)
+                else:
+                    qc = q.cpu()
+                    dist.broadcast(qc, src=0)
+                    q.copy_(qc)
                 torch.cuda.synchronize()      # the matcher runs on its own non-blocking stream: order it after the broadcast
             m.knn2_device(q.data_ptr(), NQ, db.data_ptr(), shard, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
                           idx_base=rank * shard, sync=True)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, res)
-                g = gathered.cpu().numpy()
+                dist.all_gather_into_tensor(gathered, res if cdev is dev else res.cpu())
+                g = gathered.view(world, 3, NQ).cpu().numpy()
                 return capi.merge_knn2(g[:, 0], g[:, 1], g[:, 2])
             return None
 
@@ -440,7 +454,7 @@ def main():
         barrier()
         hdt = time.perf_counter() - h0
         if world > 1:
-            tt = torch.tensor([hdt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([hdt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             hdt = float(tt.item())
         pairs = NQ * shard * world * hsteps
