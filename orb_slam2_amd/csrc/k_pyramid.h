@@ -42,12 +42,19 @@ struct __attribute__((packed, aligned(1))) RszWindow3 { uint32_t lo, hi, top; };
 
 typedef uint16_t rsz_u16x2 __attribute__((ext_vector_type(2)));
 
+// high 32 bits of the 48-bit product of two values known to fit 24 bits (v_mul_hi_u32_u24)
+__device__ __forceinline__ uint32_t rsz_mulhi24(uint32_t x, uint32_t y) {
+    uint32_t r;
+    asm("v_mul_hi_u32_u24_e32 %0, %1, %2" : "=v"(r) : "s"(x), "v"(y));   // x: wave-uniform row weight
+    return r;
+}
+
 // WIDE = false: the lane's four pixel pairs lie inside 8 bytes (scale factors up to ~1.99).  WIDE = true: 12-byte window,
 // the fourth pixel reads a view shifted by 3 bytes (two v_alignbyte_b32 per source row), good up to scale factors of 3.
 template <bool WIDE>
 __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loop in SGPRs
     if (tile >= a.nStrips * a.nRowBlocks) return;
     const int strip = tile % a.nStrips, rb = tile / a.nStrips;   // the 4 waves of a workgroup: neighbouring strips
     const int f = blockIdx.y;
@@ -98,21 +105,28 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(ResizeArgs a) {
                 hi = __builtin_amdgcn_alignbyte(raw[j].top, raw[j].hi, 3);
             }
             const uint32_t pr = __builtin_amdgcn_perm(hi, lo, sel[i]);
-            Hc[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rsz_u16x2, pr), __builtin_bit_cast(rsz_u16x2, coef[i]), 0u, false) >> 4;
+            // H >> 4 is kept in place (low 4 bits cleared): the vertical pass folds the shift into its multiplier
+            Hc[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rsz_u16x2, pr), __builtin_bit_cast(rsz_u16x2, coef[i]), 0u, false) & ~15u;
         }
         while (dy < y1) {
             const int yo = __builtin_amdgcn_readlane(ylOfs, dy - y0), yc = __builtin_amdgcn_readlane(ylCoef, dy - y0);
             const int r0 = min(max(yo, 0), a.sh - 1) - sy0, r1 = min(max(yo + 1, 0), a.sh - 1) - sy0;
             if (r1 != j) break;            // its lower source row comes later
-            const uint32_t b0 = (uint32_t)yc & 0xffffu, b1 = (uint32_t)yc >> 16;
-            const bool same = r0 == j;     // both rows clamp to the same source row (image top / bottom)
-            uint32_t out = 0;
+            // (b * (H >> 4)) >> 16 as the high half of one 24-bit multiply: (b << 12) * (H & ~15) = (b * (H >> 4)) << 16,
+            // b <= 2048 and H < 2^19, so both factors fit 24 bits and the product's bits 32.. are the wanted floor
+            const uint32_t b0 = ((uint32_t)yc & 0xffffu) << 12, b1 = ((uint32_t)yc >> 16) << 12;
+            if (r0 == j) {                 // both rows clamp to the same source row (image top / bottom): wave-uniform
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t HA = same ? Hc[i] : Hp[i];
-                const uint32_t d = ((__umul24(b0, HA) >> 16) + (__umul24(b1, Hc[i]) >> 16) + 2u) >> 2;
-                out |= (d & 0xffu) << (8 * i);
+                for (int i = 0; i < 4; i++) Hp[i] = Hc[i];   // Hp is overwritten by the next source row anyway
+                asm volatile("; top / bottom clamp" ::: "memory");   // keeps this a (rarely taken) scalar branch, not four selects per row
             }
+            uint32_t s[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[i] = rsz_mulhi24(b0, Hp[i]) + rsz_mulhi24(b1, Hc[i]) + 2u;   // <= 1023
+            // >> 2 on both 16-bit halves at once, then the four low bytes into one dword
+            const rsz_u16x2 q01 = __builtin_bit_cast(rsz_u16x2, (s[1] << 16) | s[0]) >> (uint16_t)2;
+            const rsz_u16x2 q23 = __builtin_bit_cast(rsz_u16x2, (s[3] << 16) | s[2]) >> (uint16_t)2;
+            const uint32_t out = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q23), __builtin_bit_cast(uint32_t, q01), 0x06040200u);
             if (writer) *reinterpret_cast<uint32_t *>(dstF + (size_t)dy * a.dPitch) = out;
             dy++;
         }
