@@ -56,7 +56,7 @@ constexpr uint32_t bw(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
 
 __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const BlurTile *tiles, int nTiles) {
     const int lane = threadIdx.x & 63;
-    const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ti = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile record, row addresses and row tests on the scalar unit
     if (ti >= nTiles) return;
     const BlurTile t = tiles[ti];
     const int f = blockIdx.y;

@@ -166,14 +166,14 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
     __shared__ int sCellMax[WAVES][kFastMaxCells];
     __shared__ int4 sSeg[WAVES][kFastMaxSeg];   // per segment: first lane, first cell (in wave), x and y of its origin in the output
     const int lane = threadIdx.x & 63;
-    const int ti = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile record and row tests on the scalar unit
+    const int ti = blockIdx.x * WAVES + wvi;
     if (ti >= a.nTiles) return;
     const FastTile &t = a.tiles[ti];
     const int f = blockIdx.y;
     const int level = t.level, nSeg = t.nSeg;
     const LevelGeom &L = a.g.lv[level];
     const int w = L.w, h = L.h;
-    const int wvi = threadIdx.x >> 6;
     int pitch;
     const uint8_t *img = level_ptr(a.s, a.g, f, level, &pitch);
     // the lane's segment.  Its 4 pixels start at x0 = Xs - 4 + 4 * (lane - lane0) whatever the alignment (unaligned dword
