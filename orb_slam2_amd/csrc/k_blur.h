@@ -157,9 +157,12 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
                 o3 = bdot2(VO, bw(34, 55), o3);
                 o3 = bdot2(VER, bw(49, 18), o3);
                 o3 = bdot2(VOR, bw(34, 0), o3);
-                // (o >> 16) saturated to 255 is byte 2 of min(o, 0xFFFFFF)
-                o0 = min(o0, 0xFFFFFFu); o1 = min(o1, 0xFFFFFFu); o2 = min(o2, 0xFFFFFFu); o3 = min(o3, 0xFFFFFFu);
-                const uint32_t out = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u) | __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
+                // o >> 16 (<= 257) of two pixels side by side in 16-bit halves, saturated to 255 by one packed minimum per
+                // pair, then the four low bytes into one dword
+                const blur_u16x2 k255 = bpk(bw(255, 255));
+                const blur_u16x2 h01 = __builtin_elementwise_min(bpk(__builtin_amdgcn_perm(o1, o0, 0x07060302u)), k255);
+                const blur_u16x2 h23 = __builtin_elementwise_min(bpk(__builtin_amdgcn_perm(o3, o2, 0x07060302u)), k255);
+                const uint32_t out = __builtin_amdgcn_perm(bu32(h23), bu32(h01), 0x06040200u);
                 if (writer) *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.pitch + x0) = out;   // pitch >= round_up(w,4)
             }
         }
