@@ -39,10 +39,10 @@ __device__ __forceinline__ int refl101(int p, int n) {
 }
 
 __device__ __forceinline__ uint32_t dpp_lane_m1(uint32_t v) {   // lane i <- lane i-1 (wave_shr:1), 0 into lane 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t dpp_lane_p1(uint32_t v) {   // lane i <- lane i+1 (wave_shl:1), 0 into lane 63
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
 typedef uint16_t blur_u16x2 __attribute__((ext_vector_type(2)));
@@ -86,6 +86,8 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
     const uint32_t selER = kSelER[r], selOR = kSelOR[r];
     const uint32_t xl = (uint32_t)min(max(x0, 0), pitch - 4);
     const bool hasEdge = __ballot(isLeftEdge || isRightEdge) != 0;
+    const int dPitch = L.pitch;                        // (L lives in the kernel arguments: read it once, not per row)
+    const uint32_t xw = (uint32_t)max(x0, 0);          // writers have x0 >= 0
 
     uint32_t E[7], O[7];
 #pragma unroll
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void gauss7_kernel(Geom g, ImgSrc s, const Blu
                 const blur_u16x2 h01 = __builtin_elementwise_min(bpk(__builtin_amdgcn_perm(o1, o0, 0x07060302u)), k255);
                 const blur_u16x2 h23 = __builtin_elementwise_min(bpk(__builtin_amdgcn_perm(o3, o2, 0x07060302u)), k255);
                 const uint32_t out = __builtin_amdgcn_perm(bu32(h23), bu32(h01), 0x06040200u);
-                if (writer) *reinterpret_cast<uint32_t *>(dst + (size_t)y * L.pitch + x0) = out;   // pitch >= round_up(w,4)
+                if (writer) *reinterpret_cast<uint32_t *>(dst + (size_t)y * dPitch + (size_t)xw) = out;   // wave-uniform row + 32-bit lane offset; pitch >= round_up(w,4)
             }
         }
 #pragma unroll
