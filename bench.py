@@ -385,23 +385,23 @@ def main():
     fast_bytes = frames_per_launch * (LEVEL_PIXELS + 8 * cand_per_frame)
     achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
     # traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at 512 frames per launch
-    # (profiles/r1g_pmc_summary.txt): 2 x 457.1 MB fetched (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md) +
-    # 53.5 MB written = 1.93 MB per frame; scaled to the frames one launch of this run processes.
-    traffic = int(frames_per_launch * (2 * 457063.1 + 53586.2) * 1024 / 512)
+    # (profiles/r1j_pmc_summary.txt): 2 x 456.3 MB fetched (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md) +
+    # 53.6 MB written = 1.93 MB per frame; scaled to the frames one launch of this run processes.
+    traffic = int(frames_per_launch * (2 * 456320.1 + 53624.5) * 1024 / 512)
     roofline = {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "ms_per_launch": round(fast_ms, 4), "algorithmic_bytes_per_launch": int(fast_bytes),
                 "frames_per_launch": frames_per_launch,
-                "note": "FAST is integer-VALU-bound, not HBM-bound: ~210 VALU instructions per wave and pixel row (156 of them the "
-                        "packed min/max of the arc-score network and the 3x3 suppression, at the measured 4.15 cycles), SQ_INSTS_VALU says 95 % "
-                        "issue utilisation (profiles/r1g_pmc_summary.txt); ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
+                "note": "FAST is integer-VALU-bound, not HBM-bound: ~200 VALU instructions per wave and pixel row (156 of them the "
+                        "packed min/max of the arc-score network and the 3x3 suppression, at the measured 4.15 cycles), SQ_INSTS_VALU says 97 % "
+                        "issue utilisation (profiles/r1j_pmc_summary.txt); ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
                         "--handles > 1 the other handle's kernels run concurrently and inflate it); stage_ms_per_step "
                         "comes from 5 extra un-timed steps with events around every stage",
                 "stage_ms_per_step": stages}
-    # the resource FAST is actually bound by: VALU issue slots.  SQ_INSTS_VALU of this kernel is 646.6 M wave instructions per
-    # 512-frame launch of this workload (profiles/r1g_pmc_summary.txt; the count depends on the frames, not on the run), a
+    # the resource FAST is actually bound by: VALU issue slots.  SQ_INSTS_VALU of this kernel is 618.2 M wave instructions per
+    # 512-frame launch of this workload (profiles/r1j_pmc_summary.txt; the count depends on the frames, not on the run), a
     # packed-integer instruction occupies a SIMD for 4.15 cycles (profiles/r1_valu_rates_ubench.txt), 1024 SIMDs at 2.4 GHz.
-    valu_instr = 646.6e6 / 512 * frames_per_launch
+    valu_instr = 618.2e6 / 512 * frames_per_launch
     roofline["valu_issue"] = {"wave_instructions_per_launch": int(valu_instr), "cycles_per_instruction": 4.15,
                               "frac": round(valu_instr * 4.15 / (1024 * 2.4e9 * fast_ms * 1e-3), 4) if fast_ms > 0 else None,
                               "note": "instruction count from the PMC pass in profiles/, duration live; 2.4 GHz nominal clock"}
