@@ -9,7 +9,8 @@
 //   * cv::FAST's NMS keeps p iff its score is strictly greater than its 8 neighbours' scores, where a neighbour that is
 //     no corner at t or lies outside the cell's scan range counts 0.  A survivor has S > t, so comparing against RAW
 //     neighbour scores gives the same answer: survivors(t) = {strict 3x3 local maxima inside the cell with S > t} for
-//     every t.  One score pass therefore serves both thresholds, and "re-run with minThFAST iff the post-NMS list is
+//     every t >= 1.  (t = 0 behaves as t = 1: the score cv::FAST stores is S - 1, which for S = 1 is not above the 0 of a
+//     non-corner; the host passes max(t, 1), orbfe.hip run_batch.)  One score pass therefore serves both thresholds, and "re-run with minThFAST iff the post-NMS list is
 //     empty" (:812-816) becomes: threshold = (any survivor with S > iniTh) ? iniTh : minTh, per cell.
 //
 // One kernel, fast_cells_kernel, register-sliding like the blur: one wavefront owns (one cell row) x (a strip of whole

@@ -654,6 +654,11 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.iniTh = std::max(iniTh, minTh);
         a.minTh = std::min(iniTh, minTh);
         if (iniTh < minTh) a.iniTh = a.minTh = iniTh;
+        // Threshold 0 gives what threshold 1 gives: cv::FAST stores S - 1 as a corner's score and its NMS wants that
+        // strictly above the 0 of a non-corner, so a corner with S = 1 never survives; the kernel compares raw S, so the
+        // same rule is "S > max(t, 1)" (for t >= 1 the two readings agree, see k_fast.h).
+        a.iniTh = std::max(a.iniTh, 1);
+        a.minTh = std::max(a.minTh, 1);
         if (e->fastBigList)   // a strip of an earlier batch produced more survivor records than the normal variant holds
             hipLaunchKernelGGL((fast_cells_kernel<kFastListCapMax, 1>), dim3(a.nTiles, F), dim3(64), 0, st, a);
         else

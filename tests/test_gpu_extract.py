@@ -186,9 +186,10 @@ def test_scale_factors_and_level_counts(scale, nlevels):
     assert _stage_check(img, 1200, scale, nlevels) > 300
 
 
-@pytest.mark.parametrize("ini_th,min_th", [(20, 7), (40, 5), (7, 7), (100, 30), (5, 20)])
+@pytest.mark.parametrize("ini_th,min_th", [(20, 7), (40, 5), (7, 7), (100, 30), (5, 20), (20, 0), (20, 1), (0, 0), (1, 0), (2, 1)])
 def test_fast_thresholds(ini_th, min_th):
-    """Per-cell iniTh -> minTh fallback for different threshold pairs (incl. ini < min, which the reference also accepts)."""
+    """Per-cell iniTh -> minTh fallback for different threshold pairs (incl. ini < min, which the reference also accepts).
+    Thresholds 0 and 1: cv::FAST stores S - 1, so a corner with S = 1 at threshold 0 scores 0 and never passes its NMS."""
     img = synth.textured_image(752, 480, synth.BASE_SEED + 500 + ini_th)
     img[:, :200] = (img[:, :200].astype(np.int32) // 8 + 100).astype(np.uint8)      # low-contrast band: cells that fall back
     _stage_check(img, 1000, 1.2, 8, ini_th, min_th)
@@ -224,7 +225,7 @@ def test_fuzz_configurations(case):
         nlevels -= 1
     nfeatures = int(rng.choice([30, 100, 500, 1000, 2000, 3500]))
     ini_th = int(rng.integers(8, 45))
-    min_th = int(rng.integers(2, ini_th + 1))
+    min_th = int(rng.integers(2, ini_th + 1)) if case % 5 else int(rng.integers(0, 2))   # every fifth case: minTh 0 or 1
     kind = str(rng.choice(["textured", "textured", "low_contrast", "flat_regions", "saturated", "noise"]))
     img = _fuzz_image(rng, w, h, kind, 700 + case)
     cfg = (w, h, nfeatures, scale, nlevels, ini_th, min_th, kind)
