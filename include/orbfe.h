@@ -165,6 +165,24 @@ int orbfe_matcher_destroy(orbfe_matcher *m);
 int orbfe_match_knn2(orbfe_matcher *m, const uint8_t *dev_q, int nq, const uint8_t *dev_r, int nr, int32_t idx_base,
                      int32_t *dev_best_dist, int32_t *dev_best_idx, int32_t *dev_second_dist, int sync);
 
+/* orbfe_match_knn2 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that must
+ * not reach hipMalloc / hipFree -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same results bit for bit, same kernels; the per-chunk and per-group partial results live in a
+ * file-scope device array of ORBFE_KNN2_NOALLOC_SCRATCH_BYTES (24 MiB: 20 MiB of (best, second) key pairs + 4 MiB of group
+ * triples) that every GPU the library runs on holds until the process ends, instead of the matcher's grow-only buffers.
+ * Its device address is resolved once per device in orbfe_matcher_create.  The call allocates and frees nothing.
+ * Limits: nq <= ORBFE_KNN2_NOALLOC_MAX_QUERIES, and a query / database size whose launch plan needs more scratch than the
+ * array holds is refused with ORBFE_ERR_CAPACITY and a message that names both sizes (2000 queries x 1 M references, the
+ * BASELINE.json configuration, needs 17 MiB; any database fits up to 10240 queries; beyond that the sampled pre-pass of
+ * databases >= 32768 references may not).
+ * All calls on one GPU share that GPU's array, whatever matcher or thread they come from: calls that overlap in time on one
+ * GPU race; serialise them (one stream, or an event between them).  Nothing in the array has to start at zero -- every entry
+ * a call reads was written by that call -- so the contents a previous call left behind are harmless. */
+#define ORBFE_KNN2_NOALLOC_MAX_QUERIES 65536
+#define ORBFE_KNN2_NOALLOC_SCRATCH_BYTES (24u << 20)
+int orbfe_match_knn2_noalloc(orbfe_matcher *m, const uint8_t *dev_q, int nq, const uint8_t *dev_r, int nr, int32_t idx_base,
+                             int32_t *dev_best_dist, int32_t *dev_best_idx, int32_t *dev_second_dist, int sync);
+
 /* Candidate-list form: the inner loops of SearchByProjection / Fuse / SearchBySim3 / SearchForInitialization
  * (src/ORBmatcher.cc:83-115, 372-392, 436-461, 1400-1424, ...), where the host produces for query i the candidate
  * rows cand_idx[cand_off[i] .. cand_off[i+1]) of r (GetFeaturesInArea, src/Frame.cc:327-380).  Same update rule,

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbfe_merge_knn2", "orbfe_set_profiling", "orbfe_get_profile", "orbfe_set_quadtree_mode", "orbfe_stereo_match",
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
     "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
-    "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence",
+    "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence", "orbfe_match_knn2_noalloc",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -91,6 +91,7 @@ def lib():
     L.orbfe_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.orbfe_matcher_destroy.argtypes = [vp]
     L.orbfe_match_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
+    L.orbfe_match_knn2_noalloc.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
     L.orbfe_match_csr.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     L.orbfe_stereo_rowband.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float,
                                        vp, vp, C.c_int]
@@ -299,6 +300,11 @@ class ORBmatcher:
     def knn2_device(self, q_ptr, nq, r_ptr, nr, bd_ptr, bi_ptr, sd_ptr, idx_base=0, sync=True):
         check(self._L.orbfe_match_knn2(self._h, vp(q_ptr), nq, vp(r_ptr), nr, idx_base, vp(bd_ptr), vp(bi_ptr), vp(sd_ptr),
                                        1 if sync else 0))
+
+    def knn2_noalloc_device(self, q_ptr, nq, r_ptr, nr, bd_ptr, bi_ptr, sd_ptr, idx_base=0, sync=True):
+        """orbfe_match_knn2_noalloc: the same search with its scratch in the library's static device array (no hipMalloc)."""
+        check(self._L.orbfe_match_knn2_noalloc(self._h, vp(q_ptr), nq, vp(r_ptr), nr, idx_base, vp(bd_ptr), vp(bi_ptr), vp(sd_ptr),
+                                               1 if sync else 0))
 
     def csr_device(self, q_ptr, nq, r_ptr, nr, off_ptr, idx_ptr, bd_ptr, bi_ptr, sd_ptr, sync=True):
         check(self._L.orbfe_match_csr(self._h, vp(q_ptr), nq, vp(r_ptr), nr, vp(off_ptr), vp(idx_ptr), vp(bd_ptr), vp(bi_ptr),
