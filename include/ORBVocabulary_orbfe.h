@@ -9,8 +9,6 @@
 // BowVector / FeatureVector are template parameters: any std::map<unsigned, double> / std::map<unsigned,
 // std::vector<unsigned>> subclass, i.e. DBoW2's own classes, fits.
 #pragma once
-#include <hip/hip_runtime_api.h>
-
 #include <cmath>
 #include <cstdint>
 #include <fstream>
@@ -19,6 +17,7 @@
 #include <vector>
 
 #include "orbfe.h"
+#include "orbfe_context.h"
 #include "orbfe_cv.h"
 
 namespace orbfe {
@@ -28,12 +27,11 @@ public:
     enum Weighting { TF_IDF = 0, TF = 1, IDF = 2, BINARY = 3 };                       // DBoW2::WeightingType
     enum Scoring { L1_NORM = 0, L2_NORM = 1, CHI_SQUARE = 2, KL = 3, BHATTACHARYYA = 4, DOT_PRODUCT = 5 };   // ScoringType
 
-    explicit Vocabulary(int device = 0) : device_(device) { orbfe_matcher_create(device, &m_); }
-    ~Vocabulary() {
-        for (void *p : bufs_) if (p) (void)hipFree(p);
-        orbfe_vocab_destroy(v_);
-        orbfe_matcher_destroy(m_);
-    }
+    // device < 0: the adapters' default device (environment ORBFE_DEVICE, else 0).  transform() runs on the calling thread's
+    // matcher context, so Frame::ComputeBoW (Tracking thread) and KeyFrame::ComputeBoW (LocalMapping thread) may use one
+    // vocabulary object at the same time, as they do with the reference's.
+    explicit Vocabulary(int device = -1) : device_(device < 0 ? default_device() : device) {}
+    ~Vocabulary() { orbfe_vocab_destroy(v_); }
     Vocabulary(const Vocabulary &) = delete;
     Vocabulary &operator=(const Vocabulary &) = delete;
 
@@ -94,20 +92,11 @@ public:
         const int n = descriptors.rows;
         std::vector<int32_t> leaf(n), nid(n);
         if (n > 0) {
-            const size_t need[3] = {(size_t)n * 32, (size_t)n * 4, (size_t)n * 4};
-            for (int i = 0; i < 3; i++)
-                if (need[i] > size_[i]) {
-                    if (bufs_[i]) (void)hipFree(bufs_[i]);
-                    bufs_[i] = nullptr;
-                    size_[i] = 0;
-                    if (hipMalloc(&bufs_[i], need[i]) != hipSuccess) return ORBFE_ERR_DEVICE;
-                    size_[i] = need[i];
-                }
-            (void)hipMemcpy2D(bufs_[0], 32, descriptors.data, descriptors.step, 32, n, hipMemcpyHostToDevice);
-            const int rc = orbfe_bow_transform(m_, v_, (const uint8_t *)bufs_[0], n, levelsup, (int32_t *)bufs_[1], (int32_t *)bufs_[2], 1);
+            int rc = ORBFE_OK;
+            orbfe_matcher *m = thread_matcher(&rc);
+            if (!m) return rc;
+            rc = orbfe_bow_transform_host(m, v_, descriptors.data, descriptors.step, n, levelsup, leaf.data(), nid.data());
             if (rc != ORBFE_OK) return rc;
-            (void)hipMemcpy(leaf.data(), bufs_[1], need[1], hipMemcpyDeviceToHost);
-            (void)hipMemcpy(nid.data(), bufs_[2], need[2], hipMemcpyDeviceToHost);
         }
         const bool tf = weighting_ == TF_IDF || weighting_ == TF;
         for (int i = 0; i < n; i++) {
@@ -144,13 +133,10 @@ public:
 
 private:
     int device_;
-    orbfe_matcher *m_ = nullptr;
     orbfe_vocab *v_ = nullptr;
     int k_ = 0, L_ = 0, scoring_ = 0, weighting_ = 0;
     std::vector<int32_t> wordId_;
     std::vector<double> weight_;
-    void *bufs_[3] = {nullptr, nullptr, nullptr};
-    size_t size_[3] = {0, 0, 0};
 };
 
 }  // namespace orbfe

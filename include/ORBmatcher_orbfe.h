@@ -17,15 +17,15 @@
 //     SearchForTriangulation (:657-823): orbfe::TriangulationMatcher
 // INTEGRATION.md shows the two-line patches.
 #pragma once
-#include <hip/hip_runtime_api.h>
-
 #include <climits>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <utility>
 #include <vector>
 
 #include "orbfe.h"
+#include "orbfe_context.h"
 #include "orbfe_cv.h"
 
 // body for ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
@@ -36,13 +36,9 @@ namespace orbfe {
 // Device-side replacement for the loop at src/Frame.cc:504-549.  Inputs are the members Frame already holds
 // (mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mvScaleFactors, image rows, minD = 0, maxD = mbf/mb);
 // outputs are bestDist / bestIdxR per left keypoint, exactly the values the reference's loop leaves in its locals.
+// Runs on the calling thread's matcher context (orbfe_context.h); the staging is inside liborbfe.
 class StereoRowBand {
 public:
-    explicit StereoRowBand(int device = 0) : m_(nullptr) { orbfe_matcher_create(device, &m_); }
-    ~StereoRowBand() {
-        for (void *p : bufs_) if (p) (void)hipFree(p);
-        orbfe_matcher_destroy(m_);
-    }
     int run(const std::vector<cv::KeyPoint> &kl, const cv::Mat &dl, const std::vector<cv::KeyPoint> &kr, const cv::Mat &dr,
             const std::vector<float> &scaleFactors, int nRows, float minD, float maxD, std::vector<int> &bestDist,
             std::vector<int> &bestIdxR) {
@@ -50,33 +46,14 @@ public:
         bestDist.assign(nl, 100);
         bestIdxR.assign(nl, 0);
         if (nl == 0) return ORBFE_OK;
-        const size_t need[6] = {(size_t)nl * 28, (size_t)nl * 32, (size_t)(nr ? nr : 1) * 28, (size_t)(nr ? nr : 1) * 32,
-                                (size_t)nl * 4, (size_t)nl * 4};
-        for (int i = 0; i < 6; i++)
-            if (need[i] > size_[i]) {
-                if (bufs_[i]) (void)hipFree(bufs_[i]);
-                if (hipMalloc(&bufs_[i], need[i]) != hipSuccess) return ORBFE_ERR_DEVICE;
-                size_[i] = need[i];
-            }
-        (void)hipMemcpy(bufs_[0], kl.data(), need[0], hipMemcpyHostToDevice);
-        for (int i = 0; i < nl; i++) (void)hipMemcpy((char *)bufs_[1] + (size_t)i * 32, dl.ptr(i), 32, hipMemcpyHostToDevice);
-        if (nr) {
-            (void)hipMemcpy(bufs_[2], kr.data(), (size_t)nr * 28, hipMemcpyHostToDevice);
-            for (int i = 0; i < nr; i++) (void)hipMemcpy((char *)bufs_[3] + (size_t)i * 32, dr.ptr(i), 32, hipMemcpyHostToDevice);
-        }
-        int rc = orbfe_stereo_rowband(m_, (const orbfe_keypoint *)bufs_[0], (const uint8_t *)bufs_[1], nl,
-                                      (const orbfe_keypoint *)bufs_[2], (const uint8_t *)bufs_[3], nr, scaleFactors.data(),
-                                      (int)scaleFactors.size(), nRows, minD, maxD, (int32_t *)bufs_[4], (int32_t *)bufs_[5], 1);
-        if (rc != ORBFE_OK) return rc;
-        (void)hipMemcpy(bestDist.data(), bufs_[4], (size_t)nl * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(bestIdxR.data(), bufs_[5], (size_t)nl * 4, hipMemcpyDeviceToHost);
-        return ORBFE_OK;
+        int rc = ORBFE_OK;
+        orbfe_matcher *m = thread_matcher(&rc);
+        if (!m) return rc;
+        static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
+        return orbfe_stereo_rowband_host(m, (const orbfe_keypoint *)kl.data(), dl.data, dl.step, nl, (const orbfe_keypoint *)kr.data(),
+                                         dr.data, dr.step, nr, scaleFactors.data(), (int)scaleFactors.size(), nRows, minD, maxD,
+                                         bestDist.data(), bestIdxR.data());
     }
-
-private:
-    orbfe_matcher *m_;
-    void *bufs_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t size_[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // Frame::ComputeStereoMatches (src/Frame.cc:466-640) on the device.  `left` / `right` are the liborbfe handles of the
@@ -84,11 +61,6 @@ private:
 // the Frame members; outputs are Frame::mvuRight and Frame::mvDepth.
 class StereoMatcher {
 public:
-    explicit StereoMatcher(int device = 0) : m_(nullptr) { orbfe_matcher_create(device, &m_); }
-    ~StereoMatcher() {
-        for (void *p : bufs_) if (p) (void)hipFree(p);
-        orbfe_matcher_destroy(m_);
-    }
     int ComputeStereoMatches(orbfe_extractor *left, orbfe_extractor *right, const std::vector<cv::KeyPoint> &kl, const cv::Mat &dl,
                              const std::vector<cv::KeyPoint> &kr, const cv::Mat &dr, float mbf, float mb,
                              std::vector<float> &mvuRight, std::vector<float> &mvDepth) {
@@ -96,35 +68,12 @@ public:
         mvuRight.assign(nl, -1.0f);   // :468-469
         mvDepth.assign(nl, -1.0f);
         if (nl == 0) return ORBFE_OK;
-        const size_t need[6] = {(size_t)nl * 28, (size_t)nl * 32, (size_t)(nr ? nr : 1) * 28, (size_t)(nr ? nr : 1) * 32,
-                                (size_t)nl * 4, (size_t)nl * 4};
-        for (int i = 0; i < 6; i++)
-            if (need[i] > size_[i]) {
-                if (bufs_[i]) (void)hipFree(bufs_[i]);
-                bufs_[i] = nullptr;
-                size_[i] = 0;
-                if (hipMalloc(&bufs_[i], need[i]) != hipSuccess) return ORBFE_ERR_DEVICE;
-                size_[i] = need[i];
-            }
-        (void)hipMemcpy(bufs_[0], kl.data(), need[0], hipMemcpyHostToDevice);
-        (void)hipMemcpy2D(bufs_[1], 32, dl.data, dl.step, 32, nl, hipMemcpyHostToDevice);
-        if (nr) {
-            (void)hipMemcpy(bufs_[2], kr.data(), (size_t)nr * 28, hipMemcpyHostToDevice);
-            (void)hipMemcpy2D(bufs_[3], 32, dr.data, dr.step, 32, nr, hipMemcpyHostToDevice);
-        }
-        int rc = orbfe_stereo_match(m_, left, 0, right, 0, (const orbfe_keypoint *)bufs_[0], (const uint8_t *)bufs_[1], nl,
-                                    (const orbfe_keypoint *)bufs_[2], (const uint8_t *)bufs_[3], nr, mbf, mb, (float *)bufs_[4],
-                                    (float *)bufs_[5], 1);
-        if (rc != ORBFE_OK) return rc;
-        (void)hipMemcpy(mvuRight.data(), bufs_[4], (size_t)nl * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(mvDepth.data(), bufs_[5], (size_t)nl * 4, hipMemcpyDeviceToHost);
-        return ORBFE_OK;
+        int rc = ORBFE_OK;
+        orbfe_matcher *m = thread_matcher(&rc);
+        if (!m) return rc;
+        return orbfe_stereo_match_host(m, left, 0, right, 0, (const orbfe_keypoint *)kl.data(), dl.data, dl.step, nl,
+                                       (const orbfe_keypoint *)kr.data(), dr.data, dr.step, nr, mbf, mb, mvuRight.data(), mvDepth.data());
     }
-
-private:
-    orbfe_matcher *m_;
-    void *bufs_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t size_[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:45-129) with the
@@ -178,13 +127,28 @@ struct TrackedPoint {
 };
 class ProjectionSearch {
 public:
-    explicit ProjectionSearch(int device = 0) : dev_(device), m_(nullptr), g_(nullptr) { orbfe_matcher_create(device, &m_); }
+    // owning form: its own matcher context (stream + staging) and its own grid, filled by build()
+    explicit ProjectionSearch(int device = 0) : dev_(device), m_(nullptr), g_(nullptr), owner_(true) {
+        status_ = orbfe_matcher_create(device, &m_);
+    }
+    // borrowing form: a matcher context of the calling thread and a grid that somebody else keeps alive (the pool of
+    // adapters/ORBmatcher_orbfe.cc).  n = keypoints in the grid.  With ownOrigin the cell range of a window is computed
+    // from (minX, minY) instead of the bounds the grid was built with (KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:574-586).
+    ProjectionSearch(orbfe_matcher *m, orbfe_frame_grid *g, int n, bool ownOrigin = false, float minX = 0, float minY = 0)
+        : dev_(0), m_(m), g_(g), owner_(false), n_(n), ownOrigin_(ownOrigin), originX_(minX), originY_(minY) {
+        status_ = (m && g) ? ORBFE_OK : ORBFE_ERR_ARG;
+    }
+    ProjectionSearch(const ProjectionSearch &) = delete;
+    ProjectionSearch &operator=(const ProjectionSearch &) = delete;
     ~ProjectionSearch() {
+        if (!owner_) return;
         if (g_) orbfe_frame_grid_destroy(g_);
         orbfe_matcher_destroy(m_);
     }
+    int status() const { return status_; }   // of the constructor: non-zero when no matcher context could be created
     int build(const std::vector<cv::KeyPoint> &keysUn, const cv::Mat &desc, const std::vector<float> &uRight, float minX, float minY,
               float gridElementWidthInv, float gridElementHeightInv) {
+        if (status_ != ORBFE_OK || !owner_) return status_ != ORBFE_OK ? status_ : ORBFE_ERR_ARG;
         const int n = (int)keysUn.size();
         std::vector<float> kx(n), ky(n);
         std::vector<int32_t> oct(n);
@@ -193,13 +157,15 @@ public:
             kx[i] = keysUn[i].pt.x;
             ky[i] = keysUn[i].pt.y;
             oct[i] = keysUn[i].octave;
-            for (int b = 0; b < 32; b++) d[(size_t)i * 32 + b] = desc.ptr(i)[b];
+            std::memcpy(&d[(size_t)i * 32], desc.ptr(i), 32);
         }
-        if (g_) orbfe_frame_grid_destroy(g_);
-        g_ = nullptr;
         n_ = n;
-        return orbfe_frame_grid_create(dev_, kx.data(), ky.data(), oct.data(), d.data(), uRight.empty() ? nullptr : uRight.data(), n,
-                                       minX, minY, gridElementWidthInv, gridElementHeightInv, &g_);
+        const float *ur = uRight.empty() ? nullptr : uRight.data();
+        if (g_)   // keep the device block: one copy on the context's stream instead of a hipFree / hipMalloc pair
+            return orbfe_frame_grid_update(m_, g_, kx.data(), ky.data(), oct.data(), d.data(), ur, n, minX, minY, gridElementWidthInv,
+                                           gridElementHeightInv);
+        return orbfe_frame_grid_create(dev_, kx.data(), ky.data(), oct.data(), d.data(), ur, n, minX, minY, gridElementWidthInv,
+                                       gridElementHeightInv, &g_);
     }
     // occupied[idx] != 0 where F.mvpMapPoints[idx] is set and has Observations() > 0 (:87-89); updated with the keypoints
     // this call associates (the MapPoints handed to this function are map points, i.e. observed).  matchIdx[i] is the
@@ -229,13 +195,15 @@ public:
             for (int b = 0; b < 32; b++) qd[(size_t)i * 32 + b] = pts[i].desc[b];
         }
         std::vector<orbfe_area_result> res(nq);
-        int rc = orbfe_search_area(m_, g_, q.data(), qd.data(), nq, occupied.data(), res.data());
+        orbfe_area_options opt = orbfe_area_options();
+        opt.blocked = occupied.data();
+        int rc = area(q.data(), qd.data(), nq, opt, res.data());
         if (rc != ORBFE_OK) return rc;
         std::vector<unsigned char> taken(n_, 0);                               // associations made by this call
         for (int i = 0; i < nq; i++) {
             orbfe_area_result r = res[i];
             if ((r.best_idx >= 0 && taken[r.best_idx]) || (r.best_idx2 >= 0 && taken[r.best_idx2])) {
-                rc = orbfe_search_area(m_, g_, &q[i], &qd[(size_t)i * 32], 1, occupied.data(), &r);
+                rc = area(&q[i], &qd[(size_t)i * 32], 1, opt, &r);
                 if (rc != ORBFE_OK) return rc;
                 requeried_++;
             }
@@ -256,8 +224,11 @@ public:
     // CurrentFrame.mvKeysUn[*].angle; occupied as in search().  assigned[idx] = index into pts of the MapPoint that
     // CurrentFrame.mvpMapPoints[idx] ends up with, or -1 (a keypoint taken by an unobserved MapPoint can be overwritten by
     // a later one, as in the reference); *nmatches is the reference's return value (it counts such a keypoint twice).
+    // removed (optional): the keypoints the rotation histogram un-matched (the reference writes NULL there, :1462).
     int searchLastFrame(const std::vector<TrackedPoint> &pts, const std::vector<float> &curAngles, bool checkOrientation,
-                        std::vector<unsigned char> &occupied, std::vector<int> &assigned, int *nmatches) {
+                        std::vector<unsigned char> &occupied, std::vector<int> &assigned, int *nmatches,
+                        std::vector<int> *removed = nullptr) {
+        if (removed) removed->clear();
         const int nq = (int)pts.size();
         assigned.assign(n_, -1);
         *nmatches = 0;
@@ -277,7 +248,9 @@ public:
             for (int b = 0; b < 32; b++) qd[(size_t)i * 32 + b] = pts[i].desc[b];
         }
         std::vector<orbfe_area_result> res(nq);
-        int rc = orbfe_search_area(m_, g_, q.data(), qd.data(), nq, occupied.data(), res.data());
+        orbfe_area_options opt = orbfe_area_options();
+        opt.blocked = occupied.data();
+        int rc = area(q.data(), qd.data(), nq, opt, res.data());
         if (rc != ORBFE_OK) return rc;
         const int HISTO_LENGTH = 30;
         std::vector<int> rotHist[HISTO_LENGTH];
@@ -287,7 +260,7 @@ public:
         for (int i = 0; i < nq; i++) {
             orbfe_area_result r = res[i];
             if (r.best_idx >= 0 && taken[r.best_idx]) {                        // only the best match is used here
-                rc = orbfe_search_area(m_, g_, &q[i], &qd[(size_t)i * 32], 1, occupied.data(), &r);
+                rc = area(&q[i], &qd[(size_t)i * 32], 1, opt, &r);
                 if (rc != ORBFE_OK) return rc;
                 requeried_++;
             }
@@ -314,6 +287,7 @@ public:
                 for (size_t j = 0; j < rotHist[i].size(); j++) {
                     assigned[rotHist[i][j]] = -1;
                     occupied[rotHist[i][j]] = 0;
+                    if (removed) removed->push_back(rotHist[i][j]);
                     n--;
                 }
             }
@@ -342,7 +316,9 @@ public:
     // with CurrentFrame's members, curAngles = CurrentFrame.mvKeysUn[*].angle, pts[i].angle = pKF->mvKeysUn[i].angle.
     // occupied[i2] != 0 where CurrentFrame.mvpMapPoints[i2] is set (:1541); assigned[i2] = index into pts or -1.
     int searchRelocalization(const std::vector<WindowPoint> &pts, const std::vector<float> &curAngles, int ORBdist,
-                             bool checkOrientation, std::vector<unsigned char> &occupied, std::vector<int> &assigned, int *nmatches) {
+                             bool checkOrientation, std::vector<unsigned char> &occupied, std::vector<int> &assigned, int *nmatches,
+                             std::vector<int> *removed = nullptr) {
+        if (removed) removed->clear();
         assigned.assign(n_, -1);
         *nmatches = 0;
         if ((int)curAngles.size() != n_) return ORBFE_ERR_ARG;
@@ -372,6 +348,7 @@ public:
                 for (size_t j = 0; j < rotHist[i].size(); j++) {
                     assigned[rotHist[i][j]] = -1;
                     occupied[rotHist[i][j]] = 0;
+                    if (removed) removed->push_back(rotHist[i][j]);
                     n--;
                 }
             }
@@ -437,7 +414,7 @@ public:
         }
         std::vector<orbfe_area_result> res(nq);
         orbfe_area_options opt = orbfe_area_options();
-        int rc = orbfe_search_area_ex(m_, g_, q.data(), qd.data(), nq, &opt, res.data());
+        int rc = area(q.data(), qd.data(), nq, opt, res.data());
         if (rc != ORBFE_OK) return rc;
         const int HISTO_LENGTH = 30, TH_LOW = 50;
         std::vector<int> rotHist[HISTO_LENGTH];
@@ -450,7 +427,7 @@ public:
             if ((r.best_idx >= 0 && vMatchedDistance[r.best_idx] <= r.best_dist) ||
                 (r.best_idx2 >= 0 && vMatchedDistance[r.best_idx2] <= r.best_dist2)) {
                 opt.dist_limit = vMatchedDistance.data();
-                rc = orbfe_search_area_ex(m_, g_, &q[i], &qd[(size_t)i * 32], 1, &opt, &r);
+                rc = area(&q[i], &qd[(size_t)i * 32], 1, opt, &r);
                 if (rc != ORBFE_OK) return rc;
                 requeried_++;
             }
@@ -520,13 +497,13 @@ private:
         opt.chi2_mono = 5.99;
         opt.chi2_stereo = 7.8;
         std::vector<orbfe_area_result> res(nq);
-        int rc = orbfe_search_area_ex(m_, g_, q.data(), qd.data(), nq, &opt, res.data());
+        int rc = area(q.data(), qd.data(), nq, opt, res.data());
         if (rc != ORBFE_OK) return rc;
         std::vector<unsigned char> taken(blockAccepted ? n_ : 0, 0);
         for (int i = 0; i < nq; i++) {
             orbfe_area_result r = res[i];
             if (blockAccepted && r.best_idx >= 0 && taken[r.best_idx]) {
-                rc = orbfe_search_area_ex(m_, g_, &q[i], &qd[(size_t)i * 32], 1, &opt, &r);
+                rc = area(&q[i], &qd[(size_t)i * 32], 1, opt, &r);
                 if (rc != ORBFE_OK) return rc;
                 requeried_++;
             }
@@ -540,10 +517,23 @@ private:
         }
         return ORBFE_OK;
     }
+    // one launch over nq windows with this object's query origin
+    int area(const orbfe_area_query *q, const unsigned char *qd, int nq, orbfe_area_options opt, orbfe_area_result *res) {
+        if (status_ != ORBFE_OK) return status_;
+        if (!g_) return ORBFE_ERR_ARG;
+        opt.has_query_origin = ownOrigin_ ? 1 : 0;
+        opt.query_min_x = originX_;
+        opt.query_min_y = originY_;
+        return orbfe_search_area_ex(m_, g_, q, qd, nq, &opt, res);
+    }
     int dev_;
     orbfe_matcher *m_;
     orbfe_frame_grid *g_;
+    bool owner_;
+    int status_ = ORBFE_OK;
     int n_ = 0;
+    bool ownOrigin_ = false;
+    float originX_ = 0, originY_ = 0;
     long requeried_ = 0;
 };
 
@@ -558,8 +548,12 @@ private:
 class BowMatcher {
 public:
     typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;   // DBoW2::FeatureVector
-    explicit BowMatcher(int device = 0) : m_(nullptr) { orbfe_matcher_create(device, &m_); }
-    ~BowMatcher() { orbfe_matcher_destroy(m_); }
+    explicit BowMatcher(int device = 0) : m_(nullptr), owner_(true) { status_ = orbfe_matcher_create(device, &m_); }
+    explicit BowMatcher(orbfe_matcher *borrowed) : m_(borrowed), owner_(false) { status_ = borrowed ? ORBFE_OK : ORBFE_ERR_ARG; }
+    BowMatcher(const BowMatcher &) = delete;
+    BowMatcher &operator=(const BowMatcher &) = delete;
+    ~BowMatcher() { if (owner_) orbfe_matcher_destroy(m_); }
+    int status() const { return status_; }
     int SearchByBoW(const FeatureVector &fv1, const cv::Mat &desc1, const std::vector<cv::KeyPoint> &keys1,
                     const std::vector<unsigned char> &valid1, const FeatureVector &fv2, const cv::Mat &desc2,
                     const std::vector<cv::KeyPoint> &keys2, const std::vector<unsigned char> &blocked2, int maxDist, float nnRatio,
@@ -567,6 +561,7 @@ public:
         const int n1 = (int)keys1.size(), n2 = (int)keys2.size();
         match12.assign(n1, -1);
         *nmatches = 0;
+        if (status_ != ORBFE_OK) return status_;
         // the merge walk of :180-264: nodes present in both maps, in ascending node id
         std::vector<int32_t> off1(1, 0), off2(1, 0), idx1, idx2;
         FeatureVector::const_iterator it1 = fv1.begin(), it2 = fv2.begin();
@@ -586,8 +581,8 @@ public:
         }
         if (off1.size() == 1 || n1 == 0 || n2 == 0) return ORBFE_OK;
         std::vector<unsigned char> d1((size_t)n1 * 32), d2((size_t)n2 * 32);
-        for (int i = 0; i < n1; i++) for (int b = 0; b < 32; b++) d1[(size_t)i * 32 + b] = desc1.ptr(i)[b];
-        for (int i = 0; i < n2; i++) for (int b = 0; b < 32; b++) d2[(size_t)i * 32 + b] = desc2.ptr(i)[b];
+        for (int i = 0; i < n1; i++) std::memcpy(&d1[(size_t)i * 32], desc1.ptr(i), 32);
+        for (int i = 0; i < n2; i++) std::memcpy(&d2[(size_t)i * 32], desc2.ptr(i), 32);
         const int rc = orbfe_search_by_bow(m_, d1.data(), valid1.empty() ? nullptr : valid1.data(), n1, d2.data(),
                                            blocked2.empty() ? nullptr : blocked2.data(), n2, off1.data(), idx1.data(), off2.data(),
                                            idx2.data(), (int)off1.size() - 1, maxDist, nnRatio, match12.data());
@@ -627,6 +622,8 @@ public:
 
 private:
     orbfe_matcher *m_;
+    bool owner_;
+    int status_ = ORBFE_OK;
 };
 
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823).  fv1 / fv2: pKF1->mFeatVec / pKF2->mFeatVec; hasMp1 / hasMp2:
@@ -635,8 +632,12 @@ private:
 class TriangulationMatcher {
 public:
     typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
-    explicit TriangulationMatcher(int device = 0) : m_(nullptr) { orbfe_matcher_create(device, &m_); }
-    ~TriangulationMatcher() { orbfe_matcher_destroy(m_); }
+    explicit TriangulationMatcher(int device = 0) : m_(nullptr), owner_(true) { status_ = orbfe_matcher_create(device, &m_); }
+    explicit TriangulationMatcher(orbfe_matcher *borrowed) : m_(borrowed), owner_(false) { status_ = borrowed ? ORBFE_OK : ORBFE_ERR_ARG; }
+    TriangulationMatcher(const TriangulationMatcher &) = delete;
+    TriangulationMatcher &operator=(const TriangulationMatcher &) = delete;
+    ~TriangulationMatcher() { if (owner_) orbfe_matcher_destroy(m_); }
+    int status() const { return status_; }
     int SearchForTriangulation(const FeatureVector &fv1, const cv::Mat &desc1, const std::vector<cv::KeyPoint> &keys1,
                                const std::vector<unsigned char> &hasMp1, const std::vector<float> &uRight1, const FeatureVector &fv2,
                                const cv::Mat &desc2, const std::vector<cv::KeyPoint> &keys2, const std::vector<unsigned char> &hasMp2,
@@ -646,6 +647,7 @@ public:
         const int n1 = (int)keys1.size(), n2 = (int)keys2.size();
         vMatchedPairs.clear();
         *nmatches = 0;
+        if (status_ != ORBFE_OK) return status_;
         std::vector<int32_t> off1(1, 0), off2(1, 0), idx1, idx2;                // the merge walk of :691-789
         FeatureVector::const_iterator it1 = fv1.begin(), it2 = fv2.begin();
         while (it1 != fv1.end() && it2 != fv2.end()) {
@@ -718,6 +720,8 @@ public:
 
 private:
     orbfe_matcher *m_;
+    bool owner_;
+    int status_ = ORBFE_OK;
 };
 
 }  // namespace orbfe

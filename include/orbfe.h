@@ -237,7 +237,9 @@ int orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *dev_desc, con
  * const vector<MapPoint*>&, th) (src/ORBmatcher.cc:71-115), for a batch of projected map points.  The grid is built on
  * the host from the Frame members (undistorted keypoint coordinates and octaves, descriptors, mvuRight or NULL,
  * mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv) exactly as the reference builds mGrid, and kept on the
- * device.  Host pointers throughout: these calls sit inside host loops of the reference. */
+ * device.  Host pointers throughout: these calls sit inside host loops of the reference.  A grid is read-only once built:
+ * any number of matcher contexts (threads) may search the same grid at the same time; the staging of a search belongs to
+ * the matcher context. */
 typedef struct orbfe_frame_grid orbfe_frame_grid;
 typedef struct orbfe_area_query {
     float x, y, r;                /* GetFeaturesInArea(x, y, r, min_level, max_level) */
@@ -256,6 +258,14 @@ int orbfe_frame_grid_create(int device, const float *kx, const float *ky, const 
                             const float *uright, int n, float min_x, float min_y, float width_inv, float height_inv,
                             orbfe_frame_grid **out);
 int orbfe_frame_grid_destroy(orbfe_frame_grid *g);
+/* Refill an existing grid with another frame's keypoints (same arguments as create): the device block is kept and only grows,
+ * the upload is one copy from the grid's pinned block on the matcher's stream, complete on return.  For a pool of grids that is
+ * recycled frame after frame (adapters/ORBmatcher_orbfe.cc keeps one keyed by frame id) instead of a hipMalloc / hipFree pair
+ * per Frame.  The caller must make sure no search on `g` is in flight.  No counterpart in the reference (AssignFeaturesToGrid
+ * refills the Frame's own std::vector cells, src/Frame.cc:230-246). */
+int orbfe_frame_grid_update(orbfe_matcher *m, orbfe_frame_grid *g, const float *kx, const float *ky, const int32_t *koct,
+                            const uint8_t *kdesc, const float *uright, int n, float min_x, float min_y, float width_inv,
+                            float height_inv);
 /* blocked (n bytes or NULL): keypoints the loop skips (:83-85: already associated with an observed MapPoint when the call
  * is made; associations made DURING the reference's loop are the caller's to replay).  Synchronous. */
 int orbfe_search_area(orbfe_matcher *m, orbfe_frame_grid *g, const orbfe_area_query *queries, const uint8_t *query_desc, int nq,
@@ -276,8 +286,11 @@ typedef struct orbfe_area_options {
     const int32_t *dist_limit;
     const float *inv_level_sigma2;
     int32_t nlevels;
-    int32_t pad;
+    int32_t has_query_origin;          /* non-zero: the cell range of a window is computed from (query_min_x, query_min_y) */
     double chi2_mono, chi2_stereo;
+    float query_min_x, query_min_y;    /* KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:574-586) subtracts the KeyFrame's own
+                                        * int mnMinX / mnMinY (include/KeyFrame.h:185-186) while the cells it walks were
+                                        * assigned with the Frame's float bounds (src/Frame.cc:384-385) */
 } orbfe_area_options;
 int orbfe_search_area_ex(orbfe_matcher *m, orbfe_frame_grid *g, const orbfe_area_query *queries, const uint8_t *query_desc, int nq,
                          const orbfe_area_options *opt, orbfe_area_result *results);
@@ -308,6 +321,18 @@ int orbfe_search_for_triangulation(orbfe_matcher *m, const uint8_t *desc1, const
                                    const int32_t *node_idx1, const int32_t *node_off2, const int32_t *node_idx2, int n_nodes,
                                    const float *F12, float ex, float ey, const float *scale_factors, const float *level_sigma2,
                                    int nlevels, int only_stereo, int32_t *match1);
+/* Host-pointer forms of three device-pointer calls above, for use from inside the reference's host code (Frame::ComputeBoW,
+ * Frame::ComputeStereoMatches): descriptors are rows of a cv::Mat (`*_stride` bytes apart, cv::Mat::step), keypoints are the
+ * std::vector<cv::KeyPoint> storage.  Inputs travel through the matcher context's pinned block in one copy, outputs in one
+ * copy back; synchronous; nothing is allocated once the blocks have grown to the frame size. */
+int orbfe_bow_transform_host(orbfe_matcher *m, const orbfe_vocab *v, const uint8_t *desc, size_t desc_stride, int n, int levelsup,
+                             int32_t *leaf_node, int32_t *nid);
+int orbfe_stereo_rowband_host(orbfe_matcher *m, const orbfe_keypoint *kl, const uint8_t *dl, size_t dl_stride, int nl,
+                              const orbfe_keypoint *kr, const uint8_t *dr, size_t dr_stride, int nr, const float *scale_factors,
+                              int nlevels, int nrows, float min_d, float max_d, int32_t *best_dist, int32_t *best_idx);
+int orbfe_stereo_match_host(orbfe_matcher *m, orbfe_extractor *left, int left_frame, orbfe_extractor *right, int right_frame,
+                            const orbfe_keypoint *kl, const uint8_t *dl, size_t dl_stride, int nl, const orbfe_keypoint *kr,
+                            const uint8_t *dr, size_t dr_stride, int nr, float mbf, float mb, float *uright, float *depth);
 int orbfe_matcher_synchronize(orbfe_matcher *m);
 /* the HIP stream of a context / extractor as a void* (hipStream_t), so callers can order their own work after it */
 void *orbfe_matcher_stream(orbfe_matcher *m);

@@ -2,6 +2,7 @@
 #pragma once
 #if __has_include(<opencv2/core/core.hpp>)
 #include <opencv2/core/core.hpp>
+#include <opencv2/features2d/features2d.hpp>   // cv::KeyPoint lives here in OpenCV 2.4
 #define ORBFE_HAVE_OPENCV 1
 #else
 #include "mini_cv.h"

@@ -1019,6 +1019,7 @@ struct orc_grid {
     std::vector<float> kx, ky;
     std::vector<int32_t> koct;
     float minX, minY, wInv, hInv;
+    float qMinX, qMinY;                  /* origin GetFeaturesInArea subtracts: the Frame's bounds, or a KeyFrame's int copies */
     std::vector<int32_t> cell[64][48];   /* mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS] */
 };
 
@@ -1027,6 +1028,7 @@ orc_grid *orc_grid_create(const float *kx, const float *ky, const int32_t *koct,
     orc_grid *g = new orc_grid;
     g->kx.assign(kx, kx + n); g->ky.assign(ky, ky + n); g->koct.assign(koct, koct + n);
     g->minX = min_x; g->minY = min_y; g->wInv = width_inv; g->hInv = height_inv;
+    g->qMinX = min_x; g->qMinY = min_y;
     for (int i = 0; i < n; i++) {   /* Frame::AssignFeaturesToGrid :230-246, PosInGrid :382-392 */
         const int posX = (int)std::round((kx[i] - min_x) * width_inv);
         const int posY = (int)std::round((ky[i] - min_y) * height_inv);
@@ -1038,15 +1040,19 @@ orc_grid *orc_grid_create(const float *kx, const float *ky, const int32_t *koct,
 
 void orc_grid_destroy(orc_grid *g) { delete g; }
 
+/* A KeyFrame walks the cells its Frame assigned (src/KeyFrame.cc:31-57 copies mGrid) but subtracts its own mnMinX / mnMinY,
+ * which are ints (include/KeyFrame.h:185-186, src/KeyFrame.cc:574-586): the window origin can differ from the cell origin. */
+void orc_grid_set_query_origin(orc_grid *g, float min_x, float min_y) { g->qMinX = min_x; g->qMinY = min_y; }
+
 int orc_features_in_area(const orc_grid *g, float x, float y, float r, int minLevel, int maxLevel, int32_t *out) {
     int n = 0;   /* Frame::GetFeaturesInArea :327-380 */
-    const int nMinCellX = std::max(0, (int)std::floor((x - g->minX - r) * g->wInv));
+    const int nMinCellX = std::max(0, (int)std::floor((x - g->qMinX - r) * g->wInv));
     if (nMinCellX >= 64) return 0;
-    const int nMaxCellX = std::min(64 - 1, (int)std::ceil((x - g->minX + r) * g->wInv));
+    const int nMaxCellX = std::min(64 - 1, (int)std::ceil((x - g->qMinX + r) * g->wInv));
     if (nMaxCellX < 0) return 0;
-    const int nMinCellY = std::max(0, (int)std::floor((y - g->minY - r) * g->hInv));
+    const int nMinCellY = std::max(0, (int)std::floor((y - g->qMinY - r) * g->hInv));
     if (nMinCellY >= 48) return 0;
-    const int nMaxCellY = std::min(48 - 1, (int)std::ceil((y - g->minY + r) * g->hInv));
+    const int nMaxCellY = std::min(48 - 1, (int)std::ceil((y - g->qMinY + r) * g->hInv));
     if (nMaxCellY < 0) return 0;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     for (int ix = nMinCellX; ix <= nMaxCellX; ix++)

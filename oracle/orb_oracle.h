@@ -114,6 +114,9 @@ typedef struct orc_grid orc_grid;
 orc_grid *orc_grid_create(const float *kx, const float *ky, const int32_t *koct, int n, float min_x, float min_y,
                           float width_inv, float height_inv);
 void orc_grid_destroy(orc_grid *g);
+/* KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:569-608) subtracts the KeyFrame's own int mnMinX / mnMinY from the window while
+ * the cells were assigned with the Frame's float bounds: set the window origin apart from the cell origin */
+void orc_grid_set_query_origin(orc_grid *g, float min_x, float min_y);
 /* Frame::GetFeaturesInArea (:327-380): indices in the reference's order; returns the count (out has room for n) */
 int orc_features_in_area(const orc_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out);
 /* the candidate loop of ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:71-115) for one

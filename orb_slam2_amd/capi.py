@@ -31,6 +31,7 @@ EXPORTS = [
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
     "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
     "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence", "orbfe_match_knn2_noalloc",
+    "orbfe_frame_grid_update", "orbfe_bow_transform_host", "orbfe_stereo_rowband_host", "orbfe_stereo_match_host",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -48,7 +49,8 @@ class OrbfeProfile(C.Structure):
 
 class OrbfeAreaOptions(C.Structure):
     _fields_ = [("blocked", C.c_void_p), ("dist_limit", C.c_void_p), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32),
-                ("pad", C.c_int32), ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double)]
+                ("has_query_origin", C.c_int32), ("chi2_mono", C.c_double), ("chi2_stereo", C.c_double),
+                ("query_min_x", C.c_float), ("query_min_y", C.c_float)]
 
 
 class OrbfeError(RuntimeError):
@@ -104,6 +106,7 @@ def lib():
     L.orbfe_frame_grid_create.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.POINTER(vp)]
     L.orbfe_frame_grid_destroy.argtypes = [vp]
+    L.orbfe_frame_grid_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
     L.orbfe_search_area.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]
     L.orbfe_search_area_ex.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(OrbfeAreaOptions), vp]
@@ -403,8 +406,17 @@ class FrameGrid:
                                         _np_ptr(res)))
         return res
 
+    def update(self, matcher: "ORBmatcher", kx, ky, koct, kdesc, uright, min_x, min_y, width_inv, height_inv):
+        """orbfe_frame_grid_update: refill this grid with another frame's keypoints (device block reused)."""
+        kx, ky = np.ascontiguousarray(kx, np.float32), np.ascontiguousarray(ky, np.float32)
+        koct, kdesc = np.ascontiguousarray(koct, np.int32), np.ascontiguousarray(kdesc, np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        self.n = len(kx)
+        check(self._L.orbfe_frame_grid_update(matcher._h, self._h, _np_ptr(kx), _np_ptr(ky), _np_ptr(koct), _np_ptr(kdesc),
+                                              None if ur is None else _np_ptr(ur), self.n, min_x, min_y, width_inv, height_inv))
+
     def search_ex(self, matcher: "ORBmatcher", queries: np.ndarray, qdesc: np.ndarray, blocked=None, dist_limit=None,
-                  inv_level_sigma2=None, chi2_mono=5.99, chi2_stereo=7.8) -> np.ndarray:
+                  inv_level_sigma2=None, chi2_mono=5.99, chi2_stereo=7.8, query_origin=None) -> np.ndarray:
         """orbfe_search_area_ex: the window search with the skip mask, the vMatchedDistance limit and the Fuse gate."""
         q = np.ascontiguousarray(queries, AREA_QUERY_DTYPE)
         d = np.ascontiguousarray(qdesc, np.uint8)
@@ -412,7 +424,10 @@ class FrameGrid:
         lim = None if dist_limit is None else np.ascontiguousarray(dist_limit, np.int32)
         s2 = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
         opt = OrbfeAreaOptions(None if b is None else b.ctypes.data, None if lim is None else lim.ctypes.data,
-                               None if s2 is None else s2.ctypes.data, 0 if s2 is None else len(s2), 0, chi2_mono, chi2_stereo)
+                               None if s2 is None else s2.ctypes.data, 0 if s2 is None else len(s2),
+                               0 if query_origin is None else 1, chi2_mono, chi2_stereo,
+                               0.0 if query_origin is None else float(query_origin[0]),
+                               0.0 if query_origin is None else float(query_origin[1]))
         res = np.zeros(len(q), AREA_RESULT_DTYPE)
         check(self._L.orbfe_search_area_ex(matcher._h, self._h, _np_ptr(q), _np_ptr(d), len(q), C.byref(opt), _np_ptr(res)))
         return res

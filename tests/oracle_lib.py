@@ -70,6 +70,8 @@ def lib():
         L.orc_grid_create.argtypes = [f32p, f32p, i32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_grid_destroy.argtypes = [C.c_void_p]
         L.orc_grid_destroy.restype = None
+        L.orc_grid_set_query_origin.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.orc_grid_set_query_origin.restype = None
         L.orc_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, i32p]
         L.orc_search_area.argtypes = [C.c_void_p, u8p, f32p, u8p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                                       C.c_float, u8p, i32p]
@@ -336,6 +338,11 @@ class OracleGrid:
         if getattr(self, "h", None):
             lib().orc_grid_destroy(self.h)
             self.h = None
+
+    def set_query_origin(self, min_x, min_y):
+        """windows are computed from this origin (a KeyFrame's int mnMinX / mnMinY), cells keep the Frame's"""
+        lib().orc_grid_set_query_origin(self.h, float(min_x), float(min_y))
+        return self
 
     def features_in_area(self, x, y, r, min_level, max_level):
         out = np.zeros(len(self.kx) + 1, np.int32)

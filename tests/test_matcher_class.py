@@ -1,0 +1,827 @@
+"""The drop-in ORB_SLAM2::ORBmatcher class (include/ORBmatcher.h + adapters/ORBmatcher_orbfe.cc; SURVEY.md section 8 row b):
+every one of the eleven Search* / Fuse methods of the reference interface (include/ORBmatcher.h:41-89) is driven through the
+class, with its reference signature, on stand-in Frame / KeyFrame / MapPoint objects (tests/cpp/stubs, the members
+src/ORBmatcher.cc touches), and what it leaves behind is compared with the sequential loop of the reference replayed on
+the oracle, association for association.
+
+The host geometry (projection, depth / viewing-angle / scale gates, PredictScale) is restated here in numpy float32 with
+the arithmetic of include/mini_cv.h (float accumulation in index order, norm / dot in double); the window searches and
+vocabulary-node searches are the oracle's (oracle/orb_oracle.cpp); the map bookkeeping of the Fuse overloads is restated
+from src/ORBmatcher.cc:951-971 / :1081-1096 and src/MapPoint.cc:98-109, :177-215 on a toy map.
+"""
+import ctypes
+import math
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import oracle_lib as O  # noqa: E402
+from test_guided_search import SF, SIGMA2, INV_SIGMA2, frame, noisy, shared_nodes  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+EXE = ROOT / "tests" / "cpp" / "matcher_main"
+f32 = np.float32
+
+# camera of KITTI 00-02 (Examples/Stereo/KITTI00-02.yaml:9-16); undistorted bounds as a distorted camera would give them
+# (fractional, negative minimum): Frame keeps them as floats, KeyFrame truncates them to ints (src/KeyFrame.cc:40-41)
+FX, FY, CX, CY, BF = f32(718.856), f32(718.856), f32(607.1928), f32(185.2157), f32(386.1448)
+B = f32(BF / FX)
+MINX, MAXX, MINY, MAXY = f32(-3.7), f32(1244.2), f32(-2.4), f32(378.9)
+KMINX, KMAXX, KMINY, KMAXY = int(MINX), int(MAXX), int(MINY), int(MAXY)      # C truncation
+W_INV = f32(f32(64) / f32(MAXX - MINX))                                      # src/Frame.cc:106-107
+H_INV = f32(f32(48) / f32(MAXY - MINY))
+_libm = ctypes.CDLL("libm.so.6")
+_libm.logf.restype = ctypes.c_float
+_libm.logf.argtypes = [ctypes.c_float]
+LOG_SF = f32(_libm.logf(ctypes.c_float(1.2)))                                # Frame::mfLogScaleFactor = log(mfScaleFactor)
+
+
+# ------------------------------------------------------------------ float32 geometry with mini_cv's arithmetic ------------
+def matvec(R, P):
+    """rows of P through the 3x3 R: ((r0*x + r1*y) + r2*z), every operation rounded to float32"""
+    R, P = R.astype(f32), P.astype(f32)
+    return np.stack([((R[i, 0] * P[:, 0]) + (R[i, 1] * P[:, 1])) + (R[i, 2] * P[:, 2]) for i in range(3)], 1).astype(f32)
+
+
+def rigid(R, t, P):
+    return (matvec(R, P) + t.astype(f32)[None, :]).astype(f32)
+
+
+def norm32(P):
+    return np.sqrt((P.astype(np.float64) ** 2).sum(1)).astype(f32)           # cv::norm: double accumulation, float variable
+
+
+def centre(R, t):
+    """Ow = -(R^T t)"""
+    return (-matvec(R.T.copy(), t[None, :])[0]).astype(f32)
+
+
+def predict_scale(max_dist, dist):
+    """MapPoint::PredictScale (src/MapPoint.cc:385-417) with this process's logf"""
+    out = np.zeros(len(dist), np.int32)
+    for i in range(len(dist)):
+        ratio = f32(max_dist[i]) / f32(dist[i])
+        v = f32(_libm.logf(ctypes.c_float(ratio))) / LOG_SF
+        n = int(math.ceil(float(v))) if np.isfinite(v) else 0
+        out[i] = min(max(n, 0), 7)
+    return out
+
+
+def pinhole(Pc, invz):
+    """x = X * invz; u = fx * x + cx (src/ORBmatcher.cc:331-336)"""
+    x, y = (Pc[:, 0] * invz).astype(f32), (Pc[:, 1] * invz).astype(f32)
+    return (FX * x + CX).astype(f32), (FY * y + CY).astype(f32)
+
+
+def inv_float(z):
+    return (f32(1) / z.astype(f32)).astype(f32)                               # `1/z`: float division
+
+
+def inv_double(z):
+    return (1.0 / z.astype(np.float64)).astype(f32)                           # `1.0/z`: double division, float variable
+
+
+def in_image_kf(u, v):
+    return (u >= KMINX) & (u < KMAXX) & (v >= KMINY) & (v < KMAXY)           # KeyFrame::IsInImage, int bounds
+
+
+def sim3_camera(Scw):
+    """src/ORBmatcher.cc:299-303 with mini_cv's Mat / double"""
+    sR = Scw[:3, :3].astype(f32)
+    scw = f32(math.sqrt(float((sR[0].astype(np.float64) ** 2).sum())))
+    Rcw = (sR.astype(np.float64) / float(scw)).astype(f32)
+    tcw = (Scw[:3, 3].astype(np.float64) / float(scw)).astype(f32)
+    return Rcw, tcw, centre(Rcw, tcw)
+
+
+def scale_gate(P, PO, use_normal=True):
+    """distance window, viewing angle, predicted level: (pass mask, dist, level)"""
+    dist = norm32(PO)
+    ok = ~((dist < (f32(0.8) * P["mind"]).astype(f32)) | (dist > (f32(1.2) * P["maxd"]).astype(f32)))
+    if use_normal:
+        dot = (PO.astype(np.float64) * P["normal"].astype(np.float64)).sum(1)
+        ok &= ~(dot < 0.5 * dist.astype(np.float64))
+    return ok, dist, predict_scale(P["maxd"], np.where(dist > 0, dist, f32(1)))
+
+
+# ------------------------------------------------------------------ the world --------------------------------------------
+def pose(rng, scale=1.0):
+    """a camera near the origin looking down +z: small rotation, small translation"""
+    a = rng.normal(0, 0.02 * scale, 3)
+    Rx = np.array([[1, 0, 0], [0, math.cos(a[0]), -math.sin(a[0])], [0, math.sin(a[0]), math.cos(a[0])]])
+    Ry = np.array([[math.cos(a[1]), 0, math.sin(a[1])], [0, 1, 0], [-math.sin(a[1]), 0, math.cos(a[1])]])
+    Rz = np.array([[math.cos(a[2]), -math.sin(a[2]), 0], [math.sin(a[2]), math.cos(a[2]), 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rx @ Ry @ Rz
+    T[:3, 3] = rng.normal(0, 0.3 * scale, 3)
+    return T.astype(f32)
+
+
+def view(seed, T, frame_id, nodes=None):
+    F = frame(seed)
+    V = dict(F)
+    V["T"] = T.astype(f32)
+    V["id"] = frame_id
+    V["mp"] = np.full(F["n"], -1, np.int32)
+    V["outlier"] = np.zeros(F["n"], np.uint8)
+    V["node"] = np.zeros(F["n"], np.int32) if nodes is None else nodes.astype(np.int32)
+    return V
+
+
+def grid_of(V, keyframe):
+    g = O.OracleGrid(V["kx"], V["ky"], V["oct"], V["d"], V["ur"], float(MINX), float(MINY), float(W_INV), float(H_INV))
+    if keyframe:
+        g.set_query_origin(KMINX, KMINY)
+    return g
+
+
+def points_seen_from(V, rng, sel, jitter=2.0, level_up=(0, 2), flips=10):
+    """world points that project near keypoints `sel` of view V (pose V['T']), with scale ranges that predict the keypoint's
+    level (or one above), normals towards the camera, descriptors = the keypoint's with noise.  Some are spoiled on purpose:
+    behind the camera, out of range, seen from behind -- the gates must remove them."""
+    n = len(sel)
+    R, t = V["T"][:3, :3].astype(np.float64), V["T"][:3, 3].astype(np.float64)
+    z = rng.uniform(4, 60, n)
+    behind = rng.uniform(size=n) < 0.04
+    z[behind] *= -1
+    u = V["kx"][sel] + rng.uniform(-jitter, jitter, n)
+    v = V["ky"][sel] + rng.uniform(-jitter, jitter, n)
+    Xc = np.stack([(u - float(CX)) / float(FX) * z, (v - float(CY)) / float(FY) * z, z], 1)
+    Pw = ((Xc - t[None, :]) @ R).astype(f32)                                   # R^T (Xc - t)
+    Ow = (-R.T @ t)
+    PO = Pw.astype(np.float64) - Ow[None, :]
+    dist = np.sqrt((PO ** 2).sum(1))
+    level = np.clip(V["oct"][sel] + rng.integers(level_up[0], level_up[1], n), 0, 7)
+    maxd = (dist * SF[level].astype(np.float64) * 0.97).astype(f32)
+    mind = (maxd / SF[7]).astype(f32)
+    far = rng.uniform(size=n) < 0.04
+    maxd[far] = (maxd[far] * f32(0.3)).astype(f32)                             # dist > 1.2 * maxd: out of the scale range
+    normal = (PO / dist[:, None]).astype(f32)
+    back = rng.uniform(size=n) < 0.04
+    normal[back] *= -1                                                         # seen from behind
+    return dict(pos=Pw, normal=normal, mind=mind, maxd=maxd, d=noisy(V["d"][sel], rng, flips), n=n,
+                bad=np.zeros(n, np.int32), nobs=np.full(n, 3, np.int32), inview=np.zeros(n, np.int32),
+                projx=np.zeros(n, f32), projy=np.zeros(n, f32), projxr=np.zeros(n, f32), tlevel=np.zeros(n, np.int32),
+                vcos=np.zeros(n, f32), src=np.asarray(sel).copy())
+
+
+def concat_points(*parts):
+    out = {}
+    for k in parts[0]:
+        out[k] = sum(p["n"] for p in parts) if k == "n" else np.concatenate([p[k] for p in parts])
+    return out
+
+
+def write_world(path, op, views, P, ip, fp, extra=()):
+    with open(path, "wb") as fh:
+        fh.write(np.array([op, len(views), P["n"]], np.int32).tobytes())
+        fh.write(np.array([FX, FY, CX, CY, BF, B, MINX, MAXX, MINY, MAXY, W_INV, H_INV], f32).tobytes())
+        fh.write(np.array([8], np.int32).tobytes())
+        fh.write(np.array([1.2, LOG_SF], f32).tobytes())
+        fh.write(SF.tobytes() + SIGMA2.tobytes() + INV_SIGMA2.tobytes())
+        for k in range(P["n"]):
+            fh.write(np.concatenate([P["pos"][k], P["normal"][k], [P["mind"][k], P["maxd"][k]]]).astype(f32).tobytes())
+            fh.write(P["d"][k].tobytes())
+            fh.write(np.array([P["bad"][k], P["nobs"][k], P["inview"][k]], np.int32).tobytes())
+            fh.write(np.array([P["projx"][k], P["projy"][k], P["projxr"][k]], f32).tobytes())
+            fh.write(np.array([P["tlevel"][k]], np.int32).tobytes())
+            fh.write(np.array([P["vcos"][k]], f32).tobytes())
+        for V in views:
+            fh.write(np.array([V["n"], V["id"]], np.int32).tobytes())
+            fh.write(V["T"].astype(f32).tobytes())
+            for a in (V["kx"], V["ky"], V["oct"].astype(np.int32), V["ang"], V["ur"], V["d"], V["mp"].astype(np.int32),
+                      V["outlier"].astype(np.uint8)):
+                fh.write(np.ascontiguousarray(a).tobytes())
+            fh.write(np.array([V["n"]], np.int32).tobytes())
+            fh.write(np.stack([V["node"], np.arange(V["n"])], 1).astype(np.int32).tobytes())   # addFeature in index order
+        ipa, fpa = np.zeros(8, np.int32), np.zeros(8, f32)
+        ipa[:len(ip)], fpa[:len(fp)] = ip, fp
+        fh.write(ipa.tobytes() + fpa.tobytes())
+        for a in extra:
+            fh.write(np.ascontiguousarray(a).tobytes())
+
+
+def run(tmp_path, *args, **kw):
+    case, out = tmp_path / "world.bin", tmp_path / "out.bin"
+    write_world(case, *args, **kw)
+    assert EXE.exists(), "build tests/cpp/matcher_main with make -C orb_slam2_amd/csrc"
+    r = subprocess.run([str(EXE), str(case), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.frombuffer(out.read_bytes(), np.int32)
+
+
+def rot_bin(a1, a2):
+    rot = f32(a1) - f32(a2)
+    if rot < 0:
+        rot = f32(rot + f32(360))
+    v = float(f32(rot * f32(1.0 / 30)))
+    bn = int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)                 # C round(): half away from zero
+    return 0 if bn == 30 else bn
+
+
+# ------------------------------------------------------------------ 1. SearchByProjection(Frame&, vpMapPoints, th) --------
+@pytest.mark.parametrize("th", [1.0, 3.0])
+def test_search_local_points(tmp_path, th):
+    """src/ORBmatcher.cc:45-129 as Tracking::SearchLocalPoints calls it (src/Tracking.cc:1185-1192): the MapPoints carry the
+    projection Frame::isInFrustum left in them."""
+    rng = np.random.default_rng(100)
+    V = view(41, pose(rng), 7)
+    n = V["n"]
+    nq = 2600
+    src = rng.integers(0, n, nq)
+    P = points_seen_from(V, rng, src)
+    P["projx"] = (V["kx"][src] + rng.uniform(-3, 3, nq)).astype(f32)
+    P["projy"] = (V["ky"][src] + rng.uniform(-3, 3, nq)).astype(f32)
+    P["projxr"] = np.where(V["ur"][src] > 0, V["ur"][src] + rng.uniform(-2, 2, nq), P["projx"] - 20).astype(f32)
+    P["tlevel"] = np.clip(V["oct"][src] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+    P["vcos"] = rng.choice([0.9, 0.9995], nq).astype(f32)
+    P["inview"] = (rng.uniform(size=nq) < 0.9).astype(np.int32)
+    P["bad"] = (rng.uniform(size=nq) < 0.05).astype(np.int32)
+    P["nobs"] = np.where(rng.uniform(size=nq) < 0.85, 3, 0).astype(np.int32)   # a few unobserved (temporal) points
+    # the frame already holds some associations (from TrackWithMotionModel): points of the same table, not in the list
+    held = rng.choice(n, 200, replace=False)
+    holders = rng.choice(nq, 200, replace=False)
+    V["mp"][held] = holders
+    lst = np.setdiff1d(np.arange(nq), holders).astype(np.int32)
+    rng.shuffle(lst)
+    nnratio = f32(0.8)
+    out = run(tmp_path, 1, [V], P, [1, len(lst)], [nnratio, th], extra=[lst])
+    nmatches, got = int(out[0]), out[1:1 + n]
+    # the reference loop on the oracle
+    og = grid_of(V, keyframe=False)
+    slot = V["mp"].copy()
+    want_n = 0
+    for k in lst:
+        if not P["inview"][k] or P["bad"][k]:
+            continue
+        blocked = ((slot >= 0) & (P["nobs"][np.maximum(slot, 0)] > 0)).astype(np.uint8)
+        r = f32(2.5) if float(P["vcos"][k]) > 0.998 else f32(4.0)
+        if th != 1.0:
+            r = f32(r * f32(th))
+        rs = float(f32(r * SF[P["tlevel"][k]]))
+        res = og.search(float(P["projx"][k]), float(P["projy"][k]), rs, int(P["tlevel"][k]) - 1, int(P["tlevel"][k]),
+                        float(P["projxr"][k]), rs, P["d"][k], blocked)
+        if res[5] == 0 or res[0] > 100:
+            continue
+        if res[2] == res[4] and f32(res[0]) > nnratio * f32(res[3]):
+            continue
+        slot[res[1]] = k
+        want_n += 1
+    assert np.array_equal(got, slot) and nmatches == want_n
+    assert want_n > 500 and (slot != V["mp"]).sum() > 500
+
+
+# ------------------------------------------------------------------ 2. SearchByProjection(CurrentFrame, LastFrame) -------
+@pytest.mark.parametrize("mode,check_ori", [("forward", 1), ("backward", 1), ("still", 0), ("mono", 1)])
+def test_track_with_motion_model(tmp_path, mode, check_ori):
+    """src/ORBmatcher.cc:1328-1470 as Tracking::TrackWithMotionModel calls it (src/Tracking.cc:886-892): projection of the
+    last frame's MapPoints with the current pose, level window by the motion direction, right-coordinate gate, histogram."""
+    rng = np.random.default_rng(200 + len(mode))
+    Tc = pose(rng)
+    Tl = Tc.copy()
+    dz = {"forward": 1.5, "backward": -1.5, "still": 0.1, "mono": 1.5}[mode]
+    # last camera = current camera moved back along its optical axis by dz: tlc.z = +dz
+    Tl[:3, 3] = (Tc[:3, 3].astype(np.float64) + np.array([0, 0, dz])).astype(f32)
+    Cur, Last = view(42, Tc, 11), view(43, Tl, 10)
+    n, nl = Cur["n"], Last["n"]
+    sel = rng.integers(0, n, nl)                                               # last keypoint i carries a point that projects near Cur[sel[i]]
+    P = points_seen_from(Cur, rng, sel, jitter=4.0)
+    P["nobs"] = np.where(rng.uniform(size=nl) < 0.7, 2, 0).astype(np.int32)    # UpdateLastFrame's temporal points have none
+    has = rng.uniform(size=nl) < 0.8
+    Last["mp"] = np.where(has, np.arange(nl), -1).astype(np.int32)
+    Last["outlier"] = (rng.uniform(size=nl) < 0.05).astype(np.uint8)
+    # last keypoint octave / angle as the window search reads them: around the current keypoint's
+    Last["oct"] = np.clip(Cur["oct"][sel] + rng.integers(-1, 2, nl), 0, 7).astype(np.int32)
+    Last["ang"] = np.mod(np.where(rng.uniform(size=nl) < 0.85, Cur["ang"][sel] + 12 + rng.normal(0, 2, nl), rng.uniform(0, 360, nl)),
+                         360).astype(f32)
+    held = rng.choice(n, 150, replace=False)                                   # current frame already holds a few associations
+    extra = points_seen_from(Cur, rng, held)
+    extra["nobs"] = np.where(rng.uniform(size=150) < 0.5, 2, 0).astype(np.int32)
+    Pall = concat_points(P, extra)
+    Cur["mp"][held] = nl + np.arange(150)
+    th = 15.0 if mode != "mono" else 7.0
+    out = run(tmp_path, 2, [Cur, Last], Pall, [check_ori, 1 if mode == "mono" else 0], [0.9, th])
+    nmatches, got = int(out[0]), out[1:1 + n]
+    # geometry (:1338-1381)
+    Rcw, tcw = Tc[:3, :3], Tc[:3, 3]
+    twc = centre(Rcw, tcw)
+    tlc = rigid(Tl[:3, :3], Tl[:3, 3], twc[None, :])[0]
+    mono = mode == "mono"
+    forward, backward = bool(tlc[2] > B) and not mono, bool(-tlc[2] > B) and not mono
+    assert forward == (mode == "forward") and backward == (mode == "backward")
+    Xc = rigid(Rcw, tcw, P["pos"])
+    invz = inv_double(Xc[:, 2])
+    u = ((FX * Xc[:, 0]).astype(f32) * invz + CX).astype(f32)
+    v = ((FY * Xc[:, 1]).astype(f32) * invz + CY).astype(f32)
+    ur = (u - (BF * invz).astype(f32)).astype(f32)
+    og = grid_of(Cur, keyframe=False)
+    slot = Cur["mp"].copy()
+    hist = [[] for _ in range(30)]
+    nm = overwritten = 0
+    for i in range(nl):
+        if Last["mp"][i] < 0 or Last["outlier"][i] or invz[i] < 0:
+            continue
+        if u[i] < MINX or u[i] > MAXX or v[i] < MINY or v[i] > MAXY:
+            continue
+        o = int(Last["oct"][i])
+        radius = float(f32(f32(th) * SF[o]))
+        lo, hi = (o, -1) if forward else (0, o) if backward else (o - 1, o + 1)
+        blocked = ((slot >= 0) & (Pall["nobs"][np.maximum(slot, 0)] > 0)).astype(np.uint8)
+        res = og.search(float(u[i]), float(v[i]), radius, lo, hi, float(ur[i]), radius, P["d"][i], blocked)
+        if res[5] == 0 or res[0] > 100:
+            continue
+        b = int(res[1])
+        overwritten += slot[b] >= 0
+        slot[b] = i
+        nm += 1
+        if check_ori:
+            hist[rot_bin(Last["ang"][i], Cur["ang"][b])].append(b)
+    if check_ori:
+        keep = set(O.three_maxima([len(h) for h in hist]))
+        for bn in range(30):
+            if bn not in keep:
+                for b in hist[bn]:
+                    slot[b] = -1
+                    nm -= 1
+    assert np.array_equal(got, slot) and nmatches == nm
+    assert nm > 600 and overwritten > 0
+
+
+# ------------------------------------------------------------------ 3. SearchByProjection(CurrentFrame, KeyFrame*, ...) ---
+@pytest.mark.parametrize("orb_dist,th,check_ori", [(100, 10.0, 1), (64, 3.0, 1), (100, 10.0, 0)])
+def test_relocalization_projection(tmp_path, orb_dist, th, check_ori):
+    """src/ORBmatcher.cc:1472-1599 as Tracking::Relocalization calls it (src/Tracking.cc:1453, :1467)."""
+    rng = np.random.default_rng(300 + orb_dist)
+    Tc = pose(rng)
+    Cur, KF = view(44, Tc, 21), view(45, pose(rng), 20)
+    n, nk = Cur["n"], KF["n"]
+    sel = rng.integers(0, n, nk)
+    P = points_seen_from(Cur, rng, sel, jitter=3.0, level_up=(-1, 2))
+    P["bad"] = (rng.uniform(size=nk) < 0.05).astype(np.int32)
+    KF["mp"] = np.where(rng.uniform(size=nk) < 0.8, np.arange(nk), -1).astype(np.int32)
+    KF["ang"] = np.mod(np.where(rng.uniform(size=nk) < 0.85, Cur["ang"][sel] + 15 + rng.normal(0, 2, nk), rng.uniform(0, 360, nk)),
+                       360).astype(f32)
+    found = rng.choice(nk, 120, replace=False).astype(np.int32)                # sAlreadyFound
+    held = rng.choice(n, 200, replace=False)                                   # keypoints of the current frame that are taken
+    Cur["mp"][held] = found[rng.integers(0, len(found), 200)]
+    out = run(tmp_path, 3, [Cur, KF], P, [check_ori, len(found), orb_dist], [0.9, th], extra=[found])
+    nmatches, got = int(out[0]), out[1:1 + n]
+    Rcw, tcw = Tc[:3, :3], Tc[:3, 3]
+    Ow = centre(Rcw, tcw)
+    Xc = rigid(Rcw, tcw, P["pos"])
+    invz = inv_double(Xc[:, 2])
+    u = ((FX * Xc[:, 0]).astype(f32) * invz + CX).astype(f32)
+    v = ((FY * Xc[:, 1]).astype(f32) * invz + CY).astype(f32)
+    ok, dist, level = scale_gate(P, (P["pos"] - Ow[None, :]).astype(f32), use_normal=False)
+    live = (KF["mp"] >= 0) & (P["bad"] == 0) & ~np.isin(np.arange(nk), found)
+    live &= ~((u < MINX) | (u > MAXX)) & ~((v < MINY) | (v > MAXY)) & ok
+    q = np.nonzero(live)[0]
+    radius = (f32(th) * SF[level[q]]).astype(f32)
+    occ = (Cur["mp"] >= 0).astype(np.uint8)
+    assigned, _, n_want = O.search_by_projection_reloc(grid_of(Cur, False), Cur["ang"], u[q], v[q], radius, level[q], KF["ang"][q],
+                                                       P["d"][q], orb_dist, check_ori, occ)
+    # the oracle reports where every keypoint ends up; un-matched-by-histogram keypoints are NULL in the frame
+    want = Cur["mp"].copy()
+    first, _, _ = O.search_by_projection_reloc(grid_of(Cur, False), Cur["ang"], u[q], v[q], radius, level[q], KF["ang"][q], P["d"][q],
+                                               orb_dist, 0, occ)
+    want[first >= 0] = -1                                                      # every keypoint the loop wrote ...
+    want[assigned >= 0] = q[assigned[assigned >= 0]]                           # ... keeps its point only if the histogram kept it
+    assert np.array_equal(got, want) and nmatches == n_want
+    assert n_want > 500 and (not check_ori or (first >= 0).sum() > n_want)
+
+
+# ------------------------------------------------------------------ 4. SearchByProjection(KeyFrame*, Scw, ...) ------------
+def test_sim3_projection(tmp_path):
+    """src/ORBmatcher.cc:290-403 as LoopClosing::ComputeSim3 calls it (src/LoopClosing.cc:375)."""
+    rng = np.random.default_rng(400)
+    T = pose(rng)
+    s = 1.07
+    Scw = T.copy()
+    Scw[:3, :] = (T[:3, :].astype(np.float64) * s).astype(f32)
+    KF = view(46, T, 30)
+    n = KF["n"]
+    nq = 2600
+    Rcw, tcw, Ow = sim3_camera(Scw)
+    Vs = dict(KF)
+    Vs["T"] = np.eye(4, dtype=f32)
+    Vs["T"][:3, :3], Vs["T"][:3, 3] = Rcw, tcw                                 # generate the points against the de-scaled camera
+    P = points_seen_from(Vs, rng, rng.integers(0, n, nq), jitter=3.0)
+    P["bad"] = (rng.uniform(size=nq) < 0.05).astype(np.int32)
+    matched_in = np.full(n, -1, np.int32)
+    pre = rng.choice(n, 150, replace=False)
+    matched_in[pre] = rng.choice(nq, 150, replace=False)                       # vpMatched on entry: these points are "already found"
+    lst = rng.permutation(nq).astype(np.int32)
+    th = 10
+    out = run(tmp_path, 4, [KF], P, [1, nq, th], [0.75, 0], extra=[Scw, lst, matched_in])
+    nmatches, got = int(out[0]), out[1:1 + n]
+    Pc = rigid(Rcw, tcw, P["pos"][lst])
+    invz = inv_float(Pc[:, 2])
+    u, v = pinhole(Pc, invz)
+    Pl = {k: (a[lst] if isinstance(a, np.ndarray) else a) for k, a in P.items()}
+    ok, dist, level = scale_gate(Pl, (P["pos"][lst] - Ow[None, :]).astype(f32))
+    live = (Pl["bad"] == 0) & ~np.isin(lst, matched_in[pre]) & ~(Pc[:, 2] < 0) & in_image_kf(u, v) & ok
+    q = np.nonzero(live)[0]
+    radius = (f32(th) * SF[level[q]]).astype(f32)
+    m_idx, _, n_want = O.search_by_projection_sim3(grid_of(KF, True), u[q], v[q], radius, level[q], Pl["d"][q], (matched_in >= 0).astype(np.uint8))
+    want = matched_in.copy()
+    want[m_idx[m_idx >= 0]] = lst[q[m_idx >= 0]]
+    assert np.array_equal(got, want) and nmatches == n_want
+    assert n_want > 700 and (~live).sum() > 300                                # the gates removed something too
+
+
+# ------------------------------------------------------------------ 5 / 6. SearchByBoW ------------------------------------
+def bow_views(rng):
+    n2 = frame(48)["n"]
+    node2 = rng.integers(0, 110, n2) * 5
+    V2 = view(48, pose(rng), 41, nodes=node2)
+    n1 = frame(47)["n"]
+    src = rng.integers(0, n2, n1)
+    node1 = node2[src].copy()
+    stray = rng.uniform(size=n1) < 0.15
+    node1[stray] = rng.integers(0, 700, int(stray.sum()))
+    V1 = view(47, pose(rng), 40, nodes=node1)
+    V1["d"] = noisy(V2["d"][src], rng, (0, 40))                                # side 1 really sees side 2's features
+    V1["ang"] = np.mod(np.where(rng.uniform(size=n1) < 0.8, V2["ang"][src] + 20 + rng.normal(0, 3, n1), rng.uniform(0, 360, n1)),
+                       360).astype(f32)
+    return V1, V2
+
+
+@pytest.mark.parametrize("check_ori", [1, 0])
+def test_search_by_bow_keyframe_frame(tmp_path, check_ori):
+    """src/ORBmatcher.cc:159-288 (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:765-768)."""
+    rng = np.random.default_rng(500)
+    V1, V2 = bow_views(rng)
+    n1, n2 = V1["n"], V2["n"]
+    P = points_seen_from(V1, rng, np.arange(n1))
+    P["bad"] = (rng.uniform(size=n1) < 0.05).astype(np.int32)
+    V1["mp"] = np.where(rng.uniform(size=n1) < 0.9, np.arange(n1), -1).astype(np.int32)
+    out = run(tmp_path, 5, [V1, V2], P, [check_ori], [0.7, 0])
+    nmatches, size, got = int(out[0]), int(out[1]), out[2:2 + n2]
+    valid1 = ((V1["mp"] >= 0) & (P["bad"] == 0)).astype(np.uint8)
+    off1, idx1, off2, idx2 = shared_nodes(V1["node"], V2["node"])
+    ref = O.search_by_bow(V1["d"], valid1, V2["d"], None, off1, idx1, off2, idx2, 50, 0.7)
+    before = int((ref >= 0).sum())
+    n_ref = before
+    if check_ori:
+        ref, n_ref = O.rotation_filter(V1["ang"], V2["ang"], ref)
+    want = np.full(n2, -1, np.int32)
+    want[ref[ref >= 0]] = np.nonzero(ref >= 0)[0]                              # vpMapPointMatches[idxF] = MapPoint of KF feature
+    assert size == n2 and np.array_equal(got, want) and nmatches == n_ref
+    assert n_ref > 300 and (not check_ori or n_ref < before)
+
+
+@pytest.mark.parametrize("check_ori", [1, 0])
+def test_search_by_bow_keyframe_keyframe(tmp_path, check_ori):
+    """src/ORBmatcher.cc:522-655 (LoopClosing::ComputeSim3, src/LoopClosing.cc:265): strict '<' TH_LOW, side 2 needs a good point."""
+    rng = np.random.default_rng(600)
+    V1, V2 = bow_views(rng)
+    n1, n2 = V1["n"], V2["n"]
+    P1, P2 = points_seen_from(V1, rng, np.arange(n1)), points_seen_from(V2, rng, np.arange(n2))
+    P = concat_points(P1, P2)
+    P["bad"] = (rng.uniform(size=n1 + n2) < 0.05).astype(np.int32)
+    V1["mp"] = np.where(rng.uniform(size=n1) < 0.9, np.arange(n1), -1).astype(np.int32)
+    V2["mp"] = np.where(rng.uniform(size=n2) < 0.9, n1 + np.arange(n2), -1).astype(np.int32)
+    out = run(tmp_path, 6, [V1, V2], P, [check_ori], [0.75, 0])
+    nmatches, size, got = int(out[0]), int(out[1]), out[2:2 + n1]
+    valid1 = ((V1["mp"] >= 0) & (P["bad"][:n1] == 0)).astype(np.uint8)
+    blocked2 = ((V2["mp"] < 0) | (P["bad"][n1:] != 0)).astype(np.uint8)
+    off1, idx1, off2, idx2 = shared_nodes(V1["node"], V2["node"])
+    ref = O.search_by_bow(V1["d"], valid1, V2["d"], blocked2, off1, idx1, off2, idx2, 49, 0.75)
+    before = int((ref >= 0).sum())
+    n_ref = before
+    if check_ori:
+        ref, n_ref = O.rotation_filter(V1["ang"], V2["ang"], ref)
+    want = np.where(ref >= 0, n1 + ref, -1).astype(np.int32)                   # vpMatches12[idx1] = MapPoint of KF2 feature
+    assert size == n1 and np.array_equal(got, want) and nmatches == n_ref
+    assert n_ref > 300 and (not check_ori or n_ref < before)
+
+
+# ------------------------------------------------------------------ 7. SearchForInitialization ---------------------------
+@pytest.mark.parametrize("check_ori,ratio", [(1, 0.9), (0, 0.8)])
+def test_search_for_initialization(tmp_path, check_ori, ratio):
+    """src/ORBmatcher.cc:405-520 (Tracking::MonocularInitialization, src/Tracking.cc:600-601)."""
+    rng = np.random.default_rng(700)
+    F2 = view(50, pose(rng), 51)
+    n2 = F2["n"]
+    F1 = view(49, pose(rng), 50)
+    n1 = F1["n"]
+    lvl0 = np.nonzero(F2["oct"] == 0)[0]
+    src = rng.choice(lvl0, n1)
+    F1["oct"] = np.where(rng.uniform(size=n1) < 0.8, 0, rng.integers(1, 8, n1)).astype(np.int32)
+    F1["d"] = noisy(F2["d"][src], rng, (0, 30))
+    F1["ang"] = np.mod(np.where(rng.uniform(size=n1) < 0.85, F2["ang"][src] + 8 + rng.normal(0, 2, n1), rng.uniform(0, 360, n1)),
+                       360).astype(f32)
+    prev = np.stack([F2["kx"][src] + rng.uniform(-30, 30, n1), F2["ky"][src] + rng.uniform(-30, 30, n1)], 1).astype(f32)
+    P = points_seen_from(F1, rng, np.arange(1))
+    out = run(tmp_path, 7, [F1, F2], P, [check_ori, 100], [ratio, 0], extra=[prev])
+    nmatches, got = int(out[0]), out[1:1 + n1]
+    prev_after = out[1 + n1:1 + n1 + 2 * n1].view(f32).reshape(n1, 2)
+    want, prev_want, n_want = O.search_for_initialization(grid_of(F2, False), F2["ang"], F1["oct"], F1["ang"], F1["d"], prev, 100, ratio,
+                                                          check_ori)
+    assert np.array_equal(got, want) and nmatches == n_want and np.array_equal(prev_after, prev_want)
+    assert n_want > 300
+
+
+# ------------------------------------------------------------------ 8. SearchForTriangulation ----------------------------
+@pytest.mark.parametrize("only_stereo,check_ori", [(0, 1), (1, 1), (0, 0)])
+def test_search_for_triangulation(tmp_path, only_stereo, check_ori):
+    """src/ORBmatcher.cc:657-823 (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:268): the epipole comes from the two
+    keyframe poses (:664-670)."""
+    rng = np.random.default_rng(800)
+    n2 = frame(52)["n"]
+    node2 = rng.integers(0, 90, n2) * 3
+    K2 = view(52, np.eye(4, dtype=f32), 61, nodes=node2)
+    n1 = frame(51)["n"]
+    src = rng.integers(0, n2, n1)
+    node1 = node2[src].copy()
+    stray = rng.uniform(size=n1) < 0.1
+    node1[stray] = rng.integers(0, 300, int(stray.sum()))
+    # KF1 = KF2's keypoints seen from a camera shifted along x and a little forward (so that the epipole lies in the image)
+    T1 = np.eye(4, dtype=f32)
+    T1[:3, 3] = np.array([-0.1, 0.02, -0.5], f32)
+    K1 = view(51, T1, 60, nodes=node1)
+    K1["kx"] = (K2["kx"][src] + rng.uniform(5, 60, n1)).astype(f32)
+    K1["ky"] = (K2["ky"][src] + rng.normal(0, 1.2, n1) * SF[K2["oct"][src]]).astype(f32)
+    K1["d"] = noisy(K2["d"][src], rng, (0, 45))
+    K1["ang"] = np.mod(np.where(rng.uniform(size=n1) < 0.85, K2["ang"][src] + 25 + rng.normal(0, 2, n1), rng.uniform(0, 360, n1)),
+                       360).astype(f32)
+    K1["ur"] = np.where(rng.uniform(size=n1) < 0.5, K1["kx"] - 10, -1).astype(f32)
+    F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], f32) + rng.normal(0, 2e-5, (3, 3))).astype(f32)
+    # some keypoints already have MapPoints on either side
+    mp1, mp2 = rng.uniform(size=n1) < 0.3, rng.uniform(size=n2) < 0.3
+    # epipole (:664-670): C2 = R2w * Cw1 + t2w, projected with KF2's intrinsics
+    Cw = centre(T1[:3, :3], T1[:3, 3])
+    C2 = rigid(K2["T"][:3, :3], K2["T"][:3, 3], Cw[None, :])[0]
+    invz = f32(f32(1.0) / C2[2])
+    ex = f32(f32(f32(FX * C2[0]) * invz) + CX)
+    ey = f32(f32(f32(FY * C2[1]) * invz) + CY)
+    near2 = np.hypot(K2["kx"] - ex, K2["ky"] - ey) < 14                        # mono and free around the epipole: the test at
+    K2["ur"] = np.where(near2, -1, K2["ur"]).astype(f32)                      # :743-749 has something to reject
+    mp2 &= ~near2
+    K1["ur"] = np.where(near2[src], -1, K1["ur"]).astype(f32)
+    mp1 &= ~near2[src]
+    K1["mp"] = np.where(mp1, np.arange(n1), -1).astype(np.int32)
+    K2["mp"] = np.where(mp2, n1 + np.arange(n2), -1).astype(np.int32)
+    P = concat_points(points_seen_from(K1, rng, np.arange(n1)), points_seen_from(K2, rng, np.arange(n2)))
+    out = run(tmp_path, 8, [K1, K2], P, [check_ori, only_stereo], [0.6, 0], extra=[F12])
+    nmatches, npairs = int(out[0]), int(out[1])
+    pairs = out[2:2 + 2 * npairs].reshape(-1, 2)
+    off1, idx1, off2, idx2 = shared_nodes(K1["node"], K2["node"])
+    xy1 = np.stack([K1["kx"], K1["ky"]], 1).astype(f32)
+    xy2 = np.stack([K2["kx"], K2["ky"]], 1).astype(f32)
+    want, n_want = O.search_for_triangulation(K1["d"], mp1.astype(np.uint8), K1["ur"], xy1, K1["ang"], K2["d"], mp2.astype(np.uint8),
+                                              K2["ur"], xy2, K2["oct"], K2["ang"], off1, idx1, off2, idx2, F12, ex, ey, SF, SIGMA2,
+                                              only_stereo, check_ori)
+    live = np.nonzero(want >= 0)[0]
+    assert nmatches == n_want == npairs and np.array_equal(pairs[:, 0], live) and np.array_equal(pairs[:, 1], want[live])
+    assert n_want > (30 if only_stereo else 120)
+    assert 0 < ex < 1241 and 0 < ey < 376 and near2.sum() > 3
+
+
+# ------------------------------------------------------------------ 9. SearchBySim3 --------------------------------------
+def test_search_by_sim3(tmp_path):
+    """src/ORBmatcher.cc:1102-1326 (LoopClosing::ComputeSim3, src/LoopClosing.cc:323)."""
+    rng = np.random.default_rng(900)
+    T1, T2 = pose(rng), pose(rng)
+    K1, K2 = view(53, T1, 70), view(54, T2, 71)
+    n1, n2 = K1["n"], K2["n"]
+    # relative Sim3 between the cameras: p_c1 = s12 R12 p_c2 + t12 with s12 = 1 (stereo); from the poses
+    R1, t1, R2, t2 = (a.astype(np.float64) for a in (T1[:3, :3], T1[:3, 3], T2[:3, :3], T2[:3, 3]))
+    R12 = (R1 @ R2.T).astype(f32)
+    t12 = (t1 - R1 @ R2.T @ t2).astype(f32)
+    s12 = f32(1.0)
+    # MapPoints of KF1: they project (through the Sim3) near keypoints of KF2; and the other way round; 60 % mutual
+    i1 = np.sort(rng.choice(n1, 1000, replace=False))
+    tgt2 = rng.integers(0, n2, len(i1))
+    P1 = points_seen_from(K2, rng, tgt2, jitter=2.0, flips=8)                 # carried by KF1 keypoints i1
+    keep = rng.uniform(size=len(i1)) < 0.6
+    uniq, first = np.unique(tgt2, return_index=True)
+    mutual = np.zeros(len(i1), bool)
+    mutual[first] = True
+    mutual &= keep
+    i2_m, tgt1_m = tgt2[mutual], i1[mutual]                                    # KF2 keypoint tgt2 carries a point seen near KF1 keypoint i1
+    extra2 = np.setdiff1d(rng.choice(n2, 300, replace=False), tgt2)
+    i2 = np.concatenate([i2_m, extra2])
+    tgt1 = np.concatenate([tgt1_m, rng.integers(0, n1, len(extra2))])
+    order = np.argsort(i2)
+    i2, tgt1 = i2[order], tgt1[order]
+    P2 = points_seen_from(K1, rng, tgt1, jitter=2.0, flips=8)
+    P = concat_points(P1, P2)
+    P["bad"] = (rng.uniform(size=P["n"]) < 0.03).astype(np.int32)
+    K1["mp"][i1] = np.arange(len(i1))
+    K2["mp"][i2] = len(i1) + np.arange(len(i2))
+    # vpMatches12 on entry: a few KF1 keypoints are matched already, to points that KF2 observes
+    in12 = np.full(n1, -1, np.int32)
+    pre = rng.choice(len(i1), 40, replace=False)
+    pre_pts = len(i1) + rng.choice(len(i2), 40, replace=False)
+    in12[i1[pre]] = pre_pts
+    th = 7.5
+    out = run(tmp_path, 9, [K1, K2], P, [1], [0.75, th, s12], extra=[R12, t12, in12])
+    n_found, got = int(out[0]), out[1:1 + n1]
+    # geometry: sR21 = (1/s12) R12^T, t21 = -sR21 t12 (mini_cv: double scale rounded per element)
+    sR12 = (float(s12) * R12.astype(np.float64)).astype(f32)
+    sR21 = ((1.0 / float(s12)) * R12.T.astype(np.float64)).astype(f32)
+    t21 = (-matvec(sR21, t12[None, :])[0]).astype(f32)
+    done1 = in12 >= 0
+    done2 = np.zeros(n2, bool)
+    done2[i2[pre_pts - len(i1)]] = True                                        # GetIndexInKeyFrame(pKF2) of those points
+
+    def direction(idx_from, Pfrom, bad, done, Rw, tw, sR, t):
+        live = (bad == 0) & ~done[idx_from]
+        Pa = rigid(Rw, tw, Pfrom["pos"])
+        Pb = rigid(sR, t, Pa)
+        live &= ~(Pb[:, 2] < 0)
+        invz = inv_double(np.where(Pb[:, 2] != 0, Pb[:, 2], f32(1)))
+        u, v = pinhole(Pb, invz)
+        live &= in_image_kf(u, v)
+        ok, dist, level = scale_gate(Pfrom, Pb, use_normal=False)
+        live &= ok
+        q = np.nonzero(live)[0]
+        return idx_from[q].astype(np.int32), u[q], v[q], (f32(th) * SF[level[q]]).astype(f32), level[q], Pfrom["d"][q]
+    q1 = direction(i1, P1, P["bad"][:len(i1)], done1, T1[:3, :3], T1[:3, 3], sR21, t21)
+    q2 = direction(i2, P2, P["bad"][len(i1):], done2, T2[:3, :3], T2[:3, 3], sR12, t12)
+    m12, n_want = O.search_by_sim3(grid_of(K1, True), grid_of(K2, True), q1, q2)
+    want = in12.copy()
+    want[m12 >= 0] = K2["mp"][m12[m12 >= 0]]
+    assert np.array_equal(got, want) and n_found == n_want
+    assert 150 < n_want < len(i1)
+
+
+# ------------------------------------------------------------------ 10. Fuse(KeyFrame*, vpMapPoints, th) ------------------
+def test_fuse_into_keyframe(tmp_path):
+    """src/ORBmatcher.cc:825-975 (LocalMapping::SearchInNeighbors, src/LocalMapping.cc:489, :514): selection with the
+    reprojection gate, then Replace / AddObservation in the loop's order -- points listed twice, points that an earlier
+    fusion of the same call turned bad or put into the keyframe."""
+    rng = np.random.default_rng(1000)
+    T = pose(rng)
+    KF, Other = view(55, T, 80), view(56, pose(rng), 81)
+    n = KF["n"]
+    nq = 2400
+    sel = rng.integers(0, n, nq)
+    P = points_seen_from(KF, rng, sel, jitter=1.5, flips=8)
+    # the keyframe already holds points on 40 % of its keypoints (their own entries in the table, observed by KF)
+    nheld = int(0.4 * n)
+    held = rng.choice(n, nheld, replace=False)
+    Ph = points_seen_from(KF, rng, held, jitter=0.5)
+    Pall = concat_points(P, Ph)
+    KF["mp"][held] = nq + np.arange(nheld)
+    Pall["nobs"] = rng.integers(1, 6, Pall["n"]).astype(np.int32)              # Observations(): who replaces whom (:959-962)
+    Pall["bad"][nq:] = (rng.uniform(size=nheld) < 0.05).astype(np.int32)       # a bad point in the keyframe: counted, nothing done
+    Pall["bad"][:nq] = (rng.uniform(size=nq) < 0.03).astype(np.int32)
+    # the candidates are observed by the other keyframe (Replace moves those observations)
+    on = min(nq, Other["n"])
+    Other["mp"][:on] = np.arange(on)
+    lst = np.concatenate([rng.permutation(nq), rng.choice(nq, 300), held[:50] * 0 + nq + np.arange(50), [-1, -1]]).astype(np.int32)
+    rng.shuffle(lst)                                                           # duplicates, points already in the KF, NULLs
+    th = 3.0
+    out = run(tmp_path, 10, [KF, Other], Pall, [1, len(lst)], [0.6, th], extra=[lst])
+    n_fused, got_slots = int(out[0]), out[1:1 + n]
+    state = out[1 + n:1 + n + 4 * Pall["n"]].reshape(-1, 4)                    # bad, nObs, replaced-by, index in KF
+    # --- selection on the oracle, for every listed point that passes the entry gates
+    Rcw, tcw = T[:3, :3], T[:3, 3]
+    Ow = centre(Rcw, tcw)
+    in_kf = np.zeros(Pall["n"], bool)
+    in_kf[KF["mp"][KF["mp"] >= 0]] = True
+    valid = lst >= 0
+    pts = np.where(valid, lst, 0)
+    Pc = rigid(Rcw, tcw, Pall["pos"][pts])
+    invz = inv_float(np.where(Pc[:, 2] != 0, Pc[:, 2], f32(1)))
+    u, v = pinhole(Pc, invz)
+    ur = (u - (BF * invz).astype(f32)).astype(f32)
+    Pl = {k: (a[pts] if isinstance(a, np.ndarray) else a) for k, a in Pall.items()}
+    ok, dist, level = scale_gate(Pl, (Pall["pos"][pts] - Ow[None, :]).astype(f32))
+    geom = valid & ~(Pc[:, 2] < 0) & in_image_kf(u, v) & ok
+    entry = geom & (Pall["bad"][pts] == 0) & ~in_kf[pts]
+    q = np.nonzero(entry)[0]
+    radius = (f32(th) * SF[level[q]]).astype(f32)
+    best, _ = O.fuse_select(grid_of(KF, True), INV_SIGMA2, 1, u[q], v[q], ur[q], radius, level[q], Pl["d"][q])
+    best_of = np.full(len(lst), -1, np.int32)
+    best_of[q] = best
+    # --- the loop's bookkeeping on a toy map (src/ORBmatcher.cc:951-971, src/MapPoint.cc:98-109, :177-215)
+    slots = {0: KF["mp"].copy(), 1: Other["mp"].copy()}                        # keyframe -> keypoint -> point
+    stereo = {0: KF["ur"] >= 0, 1: Other["ur"] >= 0}
+    obs = [dict() for _ in range(Pall["n"])]                                   # point -> {keyframe: keypoint}
+    for kf in (0, 1):
+        for i, p in enumerate(slots[kf]):
+            if p >= 0:
+                obs[p][kf] = i
+    bad, nobs, replaced = Pall["bad"].copy(), Pall["nobs"].copy(), np.full(Pall["n"], -1, np.int32)
+
+    def add_observation(p, kf, idx):
+        if kf in obs[p]:
+            return
+        obs[p][kf] = idx
+        nobs[p] += 2 if stereo[kf][idx] else 1
+
+    def replace(p, by):
+        if p == by:
+            return
+        mine, obs[p] = obs[p], {}
+        bad[p], replaced[p] = 1, by
+        for kf, idx in sorted(mine.items()):
+            if kf not in obs[by]:
+                slots[kf][idx] = by
+                add_observation(by, kf, idx)
+            else:
+                slots[kf][idx] = -1
+    want_fused = replaced_n = added_n = closed_n = 0
+    for k, p in enumerate(lst):
+        if p < 0 or best_of[k] < 0:
+            continue
+        if bad[p] or 0 in obs[p]:
+            closed_n += 1                                                      # closed by an earlier fusion of this call
+            continue
+        b = int(best_of[k])
+        cur = slots[0][b]
+        if cur >= 0:
+            if not bad[cur]:
+                if nobs[cur] > nobs[p]:
+                    replace(p, cur)
+                else:
+                    replace(cur, p)
+                replaced_n += 1
+        else:
+            add_observation(p, 0, b)
+            slots[0][b] = p
+            added_n += 1
+        want_fused += 1
+    assert n_fused == want_fused
+    assert np.array_equal(got_slots, slots[0])
+    assert np.array_equal(state[:, 0], bad) and np.array_equal(state[:, 1], nobs) and np.array_equal(state[:, 2], replaced)
+    assert np.array_equal(state[:, 3], np.array([o.get(0, -1) for o in obs], np.int32))
+    assert replaced_n > 200 and added_n > 200 and closed_n > 20
+
+
+# ------------------------------------------------------------------ 11. Fuse(KeyFrame*, Scw, ...) -------------------------
+def test_fuse_with_sim3(tmp_path):
+    """src/ORBmatcher.cc:977-1100 (LoopClosing::SearchAndFuse, src/LoopClosing.cc:600)."""
+    rng = np.random.default_rng(1100)
+    T = pose(rng)
+    s = 0.94
+    Scw = T.copy()
+    Scw[:3, :] = (T[:3, :].astype(np.float64) * s).astype(f32)
+    KF = view(57, T, 90)
+    n = KF["n"]
+    Rcw, tcw, Ow = sim3_camera(Scw)
+    Vs = dict(KF)
+    Vs["T"] = np.eye(4, dtype=f32)
+    Vs["T"][:3, :3], Vs["T"][:3, 3] = Rcw, tcw
+    nq = 2400
+    P = points_seen_from(Vs, rng, rng.integers(0, n, nq), jitter=1.5, flips=8)
+    nheld = int(0.4 * n)
+    held = rng.choice(n, nheld, replace=False)
+    Ph = points_seen_from(Vs, rng, held, jitter=0.5)
+    Pall = concat_points(P, Ph)
+    KF["mp"][held] = nq + np.arange(nheld)
+    Pall["bad"] = (rng.uniform(size=Pall["n"]) < 0.04).astype(np.int32)
+    lst = np.concatenate([rng.permutation(nq), nq + np.arange(60)]).astype(np.int32)   # the last 60 are in the keyframe already
+    rng.shuffle(lst)
+    th = 4.0
+    out = run(tmp_path, 11, [KF], Pall, [1, len(lst)], [0.6, th], extra=[Scw, lst])
+    n_fused, got_replace, got_slots = int(out[0]), out[1:1 + len(lst)], out[1 + len(lst):1 + len(lst) + n]
+    Pc = rigid(Rcw, tcw, Pall["pos"][lst])
+    invz = inv_double(np.where(Pc[:, 2] != 0, Pc[:, 2], f32(1)))
+    u, v = pinhole(Pc, invz)
+    Pl = {k: (a[lst] if isinstance(a, np.ndarray) else a) for k, a in Pall.items()}
+    ok, dist, level = scale_gate(Pl, (Pall["pos"][lst] - Ow[None, :]).astype(f32))
+    found = np.zeros(Pall["n"], bool)                                          # spAlreadyFound = the keyframe's good points
+    hp = KF["mp"][KF["mp"] >= 0]
+    found[hp[Pall["bad"][hp] == 0]] = True
+    live = (Pall["bad"][lst] == 0) & ~found[lst] & ~(Pc[:, 2] < 0) & in_image_kf(u, v) & ok
+    q = np.nonzero(live)[0]
+    radius = (f32(th) * SF[level[q]]).astype(f32)
+    best, _ = O.fuse_select(grid_of(KF, True), INV_SIGMA2, 0, u[q], v[q], np.zeros(len(q), f32), radius, level[q], Pl["d"][q])
+    slots = KF["mp"].copy()
+    want_replace = np.full(len(lst), -1, np.int32)
+    want_fused = 0
+    for a, k in enumerate(q):
+        if best[a] < 0:
+            continue
+        cur = slots[best[a]]
+        if cur >= 0:
+            if not Pall["bad"][cur]:
+                want_replace[k] = cur
+        else:
+            slots[best[a]] = lst[k]                                            # AddMapPoint: a later point finds it there
+        want_fused += 1
+    assert n_fused == want_fused and np.array_equal(got_replace, want_replace) and np.array_equal(got_slots, slots)
+    assert want_fused > 800 and (want_replace >= 0).sum() > 200 and (slots != KF["mp"]).sum() > 200
+
+
+def test_constants_and_descriptor_distance(tmp_path):
+    """TH_LOW / TH_HIGH / HISTO_LENGTH (src/ORBmatcher.cc:37-39; read by src/Frame.cc:471, :522) and the static
+    DescriptorDistance (:1647-1663; called from src/Frame.cc:541 and src/MapPoint.cc:281)."""
+    rng = np.random.default_rng(1200)
+    V = view(41, pose(rng), 1)
+    P = points_seen_from(V, rng, np.arange(1))
+    out = run(tmp_path, 12, [V], P, [1], [0.6, 0])
+    assert out[:3].tolist() == [50, 100, 30]
+    assert int(out[3]) == O.lib().orc_hamming(O._ptr(V["d"][0], O.u8p), O._ptr(V["d"][1], O.u8p))
