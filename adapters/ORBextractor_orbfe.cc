@@ -40,6 +40,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
         orbfe_die("tables");
     mvImagePyramid.resize(nlevels);
     pyramidStore_.resize(nlevels);
+    if (const char *mir = std::getenv("ORBFE_PYRAMID_MIRROR")) mirrorPyramid_ = std::atoi(mir) != 0;
 }
 
 ORBextractor::~ORBextractor() { orbfe_extractor_destroy(handle_); }
@@ -74,16 +75,22 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     _keypoints.resize(n);
     if (n) std::memcpy((void *)_keypoints.data(), kps.data(), (size_t)n * sizeof(orbfe_keypoint));
 
-    // mvImagePyramid: host copies with the reference's 19-px frame; the Mat is the ROI inside it (:1113-1115)
+    // mvImagePyramid: host copies with the reference's 19-px frame; the Mat is the ROI inside it (:1113-1115).  Only
+    // Frame::ComputeStereoMatches reads them (src/Frame.cc:473,563,575,580): with its body replaced by orbfe::StereoMatcher
+    // (INTEGRATION.md section 3), or in a monocular / RGB-D system, ORBFE_PYRAMID_MIRROR=0 saves the copy.
+    if (!mirrorPyramid_) return;
+    std::vector<unsigned char *> dst(nlevels);
+    std::vector<size_t> bytes(nlevels);
+    std::vector<int> lw(nlevels), lh(nlevels);
     for (int l = 0; l < nlevels; l++) {
-        int w = 0, h = 0;
-        if (orbfe_pyramid_level(handle_, 0, l, nullptr, 0, &w, &h) != ORBFE_OK) orbfe_die("pyramid size");
-        const int bw = w + 38, bh = h + 38;
-        pyramidStore_[l].resize((size_t)bw * bh);
-        if (orbfe_pyramid_level(handle_, 0, l, pyramidStore_[l].data(), pyramidStore_[l].size(), &w, &h) != ORBFE_OK)
-            orbfe_die("pyramid copy");
-        mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, pyramidStore_[l].data() + (size_t)19 * bw + 19, (size_t)bw);
+        if (orbfe_pyramid_level(handle_, 0, l, nullptr, 0, &lw[l], &lh[l]) != ORBFE_OK) orbfe_die("pyramid size");
+        pyramidStore_[l].resize((size_t)(lw[l] + 38) * (lh[l] + 38));
+        dst[l] = pyramidStore_[l].data();
+        bytes[l] = pyramidStore_[l].size();
     }
+    if (orbfe_pyramid_mirror(handle_, 0, dst.data(), bytes.data(), nlevels) != ORBFE_OK) orbfe_die("pyramid copy");
+    for (int l = 0; l < nlevels; l++)
+        mvImagePyramid[l] = cv::Mat(lh[l], lw[l], CV_8UC1, pyramidStore_[l].data() + (size_t)19 * (lw[l] + 38) + 19, (size_t)(lw[l] + 38));
 }
 
 }  // namespace ORB_SLAM2

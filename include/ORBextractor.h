@@ -36,7 +36,8 @@ public:
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
     // ROI views (19-px BORDER_REFLECT_101 frame around each) into host copies of the device pyramid; refreshed by every
-    // operator() call exactly as the reference re-allocates them (src/ORBextractor.cc:1113-1115).
+    // operator() call exactly as the reference re-allocates them (src/ORBextractor.cc:1113-1115), unless the environment
+    // says ORBFE_PYRAMID_MIRROR=0 (only Frame::ComputeStereoMatches reads them, src/Frame.cc:473,563,575,580).
     std::vector<cv::Mat> mvImagePyramid;
 
     // Not in the reference: the liborbfe handle behind this object, for the device-side stereo matcher
@@ -59,6 +60,7 @@ protected:
 private:
     orbfe_extractor *handle_;
     std::vector<std::vector<unsigned char> > pyramidStore_;
+    bool mirrorPyramid_ = true;   // environment ORBFE_PYRAMID_MIRROR=0: mvImagePyramid is left empty (nothing reads it)
 };
 
 }  // namespace ORB_SLAM2

@@ -110,6 +110,11 @@ int orbfe_extract_sequence(orbfe_extractor *e, const uint8_t *host_imgs, int n_f
  * (src/ORBextractor.cc:1113-1128); the ROI the reference exposes starts at dst + 19*(w+38) + 19.
  * dst may be NULL to query the size only. */
 int orbfe_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst, size_t dst_bytes, int *w, int *h);
+/* All levels of frame `frame` of the last call at once, each into its own buffer laid out as above (dst[l] holds
+ * (w_l+38) x (h_l+38) bytes; sizes from orbfe_pyramid_level with dst = NULL): two device-to-host copies into pinned memory
+ * and one wait for the whole pyramid instead of a copy and a wait per level.  This is what refreshes mvImagePyramid after
+ * every operator() in adapters/ORBextractor_orbfe.cc. */
+int orbfe_pyramid_mirror(orbfe_extractor *e, int frame, uint8_t *const *dst, const size_t *dst_bytes, int nlevels);
 
 /* Stage outputs of the last call, for stage-wise parity tests (no counterpart in the reference; its stages are
  * private members, include/ORBextractor.h:87-95).  what: 0 = pyramid level ROI (u8 w*h), 1 = blurred level (u8 w*h),

@@ -31,7 +31,7 @@ EXPORTS = [
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
     "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
     "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence", "orbfe_match_knn2_noalloc",
-    "orbfe_frame_grid_update", "orbfe_bow_transform_host", "orbfe_stereo_rowband_host", "orbfe_stereo_match_host",
+    "orbfe_frame_grid_update", "orbfe_pyramid_mirror", "orbfe_bow_transform_host", "orbfe_stereo_rowband_host", "orbfe_stereo_match_host",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")

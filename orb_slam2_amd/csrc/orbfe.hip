@@ -129,6 +129,7 @@ struct orbfe_extractor {
     // single-image path
     DevBuf dImg, dKps, dDesc, dCounts;
     PinBuf hImg, hKps, hDesc, hCounts;
+    PinBuf hMirror;                     // orbfe_pyramid_mirror: level 0 + the frame's pyramid block
     // last call (for orbfe_pyramid_level / orbfe_debug_stage)
     ImgSrc last{};
     int lastFrames = 0;
@@ -458,6 +459,25 @@ void ordered_candidates(const orbfe_extractor *e, int f, int l, std::vector<Cand
     for (int c = 0; c < L.nCols * L.nRows; c++) {
         const int off = tab[c].x, n = tab[c].y;
         for (int k = 0; k < n && off + k < L.candCap; k++) out.push_back(cand[off + k]);
+    }
+}
+
+// copyMakeBorder(..., BORDER_REFLECT_101) (:1122-1128) around a w x h ROI that sits kEdge pixels inside `buf` (row pitch
+// w + 2 kEdge): the frame is API surface only, built on the host
+void reflect101_frame(uint8_t *buf, int w, int h) {
+    const int bw = w + 2 * kEdge;
+    uint8_t *roi = buf + (size_t)kEdge * bw + kEdge;
+    auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
+    for (int y = 0; y < h; y++) {
+        uint8_t *row = roi + (size_t)y * bw;
+        for (int k = 1; k <= kEdge; k++) {
+            row[-k] = row[refl(-k, w)];
+            row[w - 1 + k] = row[refl(w - 1 + k, w)];
+        }
+    }
+    for (int k = 1; k <= kEdge; k++) {
+        memcpy(buf + (size_t)(kEdge - k) * bw, buf + (size_t)(kEdge + refl(-k, h)) * bw, bw);
+        memcpy(buf + (size_t)(kEdge + h - 1 + k) * bw, buf + (size_t)(kEdge + refl(h - 1 + k, h)) * bw, bw);
     }
 }
 
@@ -850,7 +870,7 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->seqIn[0], &e->seqIn[1], &e->seqKps[0], &e->seqKps[1],
                       &e->seqDesc[0], &e->seqDesc[1], &e->seqCnt[0], &e->seqCnt[1]})
         b->release();
-    for (PinBuf *b : {&e->hImg, &e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus})
+    for (PinBuf *b : {&e->hImg, &e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus, &e->hMirror})
         b->release();
     delete e;
     return ORBFE_OK;
@@ -1072,18 +1092,35 @@ int orbfe_pyramid_level(orbfe_extractor *e, int frame, int level, uint8_t *dst, 
     uint8_t *roi = dst + (size_t)kEdge * bw + kEdge;
     HIPCHK(hipMemcpy2DAsync(roi, bw, src, pitch, L.w, L.h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    // copyMakeBorder(..., BORDER_REFLECT_101) (:1122-1128): the frame is API surface only, built on the host
-    auto refl = [](int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; };
-    for (int y = 0; y < L.h; y++) {
-        uint8_t *row = roi + (size_t)y * bw;
-        for (int k = 1; k <= kEdge; k++) {
-            row[-k] = row[refl(-k, L.w)];
-            row[L.w - 1 + k] = row[refl(L.w - 1 + k, L.w)];
-        }
-    }
-    for (int k = 1; k <= kEdge; k++) {
-        memcpy(dst + (size_t)(kEdge - k) * bw, dst + (size_t)(kEdge + refl(-k, L.h)) * bw, bw);
-        memcpy(dst + (size_t)(kEdge + L.h - 1 + k) * bw, dst + (size_t)(kEdge + refl(L.h - 1 + k, L.h)) * bw, bw);
+    reflect101_frame(dst, L.w, L.h);
+    return ORBFE_OK;
+}
+
+int orbfe_pyramid_mirror(orbfe_extractor *e, int frame, uint8_t *const *dst, const size_t *dst_bytes, int nlevels) {
+    if (!e || !e->haveGeom || e->lastFrames == 0) return fail(ORBFE_ERR_ARG, "no extraction has run on this handle");
+    if (frame < 0 || frame >= e->lastFrames || !dst || !dst_bytes || nlevels != e->g.nlevels) return fail(ORBFE_ERR_ARG, "bad argument");
+    const Geom &g = e->g;
+    for (int l = 0; l < nlevels; l++)
+        if (!dst[l] || dst_bytes[l] < (size_t)(g.lv[l].w + 2 * kEdge) * (g.lv[l].h + 2 * kEdge))
+            return fail(ORBFE_ERR_CAPACITY, "destination too small");
+    HIPCHK(hipSetDevice(e->device));
+    // level 0 (the caller's frame) and the frame's block of levels 1.. come over in two copies into pinned memory, one wait
+    const size_t l0Bytes = (size_t)e->last.pitch0 * g.h0, pyrBytes = nlevels > 1 ? (size_t)g.pyrFrameBytes : 0;
+    const size_t l0Pad = (l0Bytes + 63) & ~(size_t)63;
+    HIPCHK(e->hMirror.ensure(l0Pad + pyrBytes + 64));
+    uint8_t *h0 = (uint8_t *)e->hMirror.p, *hp = h0 + l0Pad;
+    HIPCHK(hipMemcpyAsync(h0, e->last.img0 + (size_t)frame * e->last.frameStride0, l0Bytes, hipMemcpyDeviceToHost, e->stream));
+    if (pyrBytes)
+        HIPCHK(hipMemcpyAsync(hp, e->last.pyr + (size_t)frame * g.pyrFrameBytes, pyrBytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int l = 0; l < nlevels; l++) {
+        const LevelGeom &L = g.lv[l];
+        const int bw = L.w + 2 * kEdge;
+        const uint8_t *src = l == 0 ? h0 : hp + L.pyrOff;
+        const int pitch = l == 0 ? e->last.pitch0 : L.pitch;
+        uint8_t *roi = dst[l] + (size_t)kEdge * bw + kEdge;
+        for (int y = 0; y < L.h; y++) memcpy(roi + (size_t)y * bw, src + (size_t)y * pitch, (size_t)L.w);
+        reflect101_frame(dst[l], L.w, L.h);
     }
     return ORBFE_OK;
 }

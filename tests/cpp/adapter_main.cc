@@ -19,6 +19,8 @@
 // and a list of projected map points read from case.bin (layout in tests/test_gpu_adapter.py).
 // The bow mode loads a vocabulary in the ORBvoc.txt format and runs Frame::ComputeBoW's transform (src/Frame.cc:395-402).
 // The stereo mode follows the Frame stereo constructor (src/Frame.cc:59-93): two extractors, then ComputeStereoMatches.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -352,7 +354,39 @@ static int triangulate_main(char **argv) {
     return 0;
 }
 
+// latency mode: wall clock around ORBextractor::operator() on one host image, as Examples/Monocular/mono_tum.cc:88-104 times
+// TrackMonocular (steady_clock, median over the frames); once with the mvImagePyramid mirror and once without.
+//   adapter_main latency in.raw w h nfeatures reps
+static int latency_main(char **argv) {
+    const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), nf = std::atoi(argv[5]), reps = std::atoi(argv[6]);
+    std::vector<unsigned char> buf((size_t)w * h);
+    if (!read_raw(argv[2], buf)) return 3;
+    cv::Mat im(h, w, CV_8UC1, buf.data(), (size_t)w);
+    double med[2] = {0, 0};
+    int nkp = 0;
+    for (int mirror = 1; mirror >= 0; mirror--) {
+        setenv("ORBFE_PYRAMID_MIRROR", mirror ? "1" : "0", 1);
+        ORB_SLAM2::ORBextractor ex(nf, 1.2f, 8, 20, 7);
+        std::vector<cv::KeyPoint> keys;
+        cv::Mat desc;
+        for (int i = 0; i < 5; i++) ex(im, cv::Mat(), keys, desc);   // warm-up: workspace allocation, code object load
+        std::vector<double> t(reps);
+        for (int i = 0; i < reps; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            ex(im, cv::Mat(), keys, desc);
+            t[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        std::sort(t.begin(), t.end());
+        med[1 - mirror] = t[reps / 2];
+        nkp = (int)keys.size();
+    }
+    std::printf("{\"median_ms_with_pyramid_mirror\": %.4f, \"median_ms_without_pyramid_mirror\": %.4f, \"keypoints\": %d, \"reps\": %d}\n",
+                med[0], med[1], nkp, reps);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 7 && std::strcmp(argv[1], "latency") == 0) return latency_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "guided") == 0) return guided_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "triangulate") == 0) return triangulate_main(argv);
     if (argc >= 4 && std::strcmp(argv[1], "bowmatch") == 0) return bowmatch_main(argv);
