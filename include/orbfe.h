@@ -350,6 +350,28 @@ void *orbfe_extractor_stream(orbfe_extractor *e);
 int orbfe_merge_knn2(const int32_t *best_dist, const int32_t *best_idx, const int32_t *second_dist, int n_shards, int nq,
                      int32_t *out_best_dist, int32_t *out_best_idx, int32_t *out_second_dist);
 
+/* The same search with the exchange inside the library, for a C++ host with one process per GPU (SURVEY.md section 8b / 8e;
+ * BASELINE.json configs[4]: 2000 queries against 1 M map-point descriptors sharded over 8 GPUs).  No counterpart in the
+ * reference (single process, no collectives).  RCCL over xGMI: ncclBroadcast of the query batch from rank 0 (nq x 32 bytes),
+ * the local scan (orbfe_match_knn2 on this rank's shard), ncclAllGather of the per-shard triples (12 bytes per query and
+ * rank -- latency-bound, far below a link's bandwidth) and the fold of orbfe_merge_knn2 as a kernel, all on the matcher's
+ * stream; every rank ends up with the unsharded answer in device memory.  librccl.so.1 is bound at run time (the copy the
+ * process already holds, else the system's); without it these calls fail with ORBFE_ERR_DEVICE and nothing else is affected.
+ *   unique_id  rank 0 creates the 128-byte id and ships it to the other ranks by its own means (MPI, a file, a socket, torch)
+ *   create     collective over all ranks of the job: ncclCommInitRank on the matcher's device; max_queries sizes the buffers
+ *   run        collective; dev_q holds the queries on rank 0 and receives them elsewhere; dev_shard / n_shard / idx_base as in
+ *              orbfe_match_knn2 (idx_base = global index of the shard's first descriptor)
+ * The exchange has run on hardware with one rank only (tests/test_gpu_match.py); more ranks need more GPUs than the
+ * development box has -- see DESIGN.md section 6. */
+#define ORBFE_SHARDED_ID_BYTES 128
+typedef struct orbfe_knn2_sharded orbfe_knn2_sharded;
+int orbfe_knn2_sharded_unique_id(uint8_t id[ORBFE_SHARDED_ID_BYTES]);
+int orbfe_knn2_sharded_create(orbfe_matcher *m, const uint8_t id[ORBFE_SHARDED_ID_BYTES], int rank, int world, int max_queries,
+                              orbfe_knn2_sharded **out);
+int orbfe_knn2_sharded_run(orbfe_knn2_sharded *s, uint8_t *dev_q, int nq, const uint8_t *dev_shard, int n_shard, int32_t idx_base,
+                           int32_t *dev_best_dist, int32_t *dev_best_idx, int32_t *dev_second_dist, int sync);
+int orbfe_knn2_sharded_destroy(orbfe_knn2_sharded *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ EXPORTS = [
     "orbfe_vocab_create", "orbfe_vocab_destroy", "orbfe_bow_transform", "orbfe_distinctive_descriptors",
     "orbfe_frame_grid_create", "orbfe_frame_grid_destroy", "orbfe_search_area", "orbfe_search_by_bow",
     "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence", "orbfe_match_knn2_noalloc",
+    "orbfe_knn2_sharded_unique_id", "orbfe_knn2_sharded_create", "orbfe_knn2_sharded_run", "orbfe_knn2_sharded_destroy",
     "orbfe_frame_grid_update", "orbfe_pyramid_mirror", "orbfe_bow_transform_host", "orbfe_stereo_rowband_host", "orbfe_stereo_match_host",
 ]
 
@@ -94,6 +95,10 @@ def lib():
     L.orbfe_matcher_destroy.argtypes = [vp]
     L.orbfe_match_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
     L.orbfe_match_knn2_noalloc.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
+    L.orbfe_knn2_sharded_unique_id.argtypes = [vp]
+    L.orbfe_knn2_sharded_create.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.orbfe_knn2_sharded_run.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
+    L.orbfe_knn2_sharded_destroy.argtypes = [vp]
     L.orbfe_match_csr.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     L.orbfe_stereo_rowband.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float,
                                        vp, vp, C.c_int]
@@ -375,6 +380,38 @@ class ORBmatcher:
 
     def stream(self) -> int:
         return int(self._L.orbfe_matcher_stream(self._h) or 0)
+
+
+def sharded_unique_id() -> bytes:
+    """orbfe_knn2_sharded_unique_id: rank 0 makes the 128-byte RCCL id; ship it to the other ranks before ShardedKnn2()."""
+    buf = (C.c_uint8 * 128)()
+    check(lib().orbfe_knn2_sharded_unique_id(buf))
+    return bytes(buf)
+
+
+class ShardedKnn2:
+    """orbfe_knn2_sharded_*: kNN-2 against a database sharded over the ranks, RCCL broadcast + all-gather inside liborbfe."""
+
+    def __init__(self, matcher: "ORBmatcher", unique_id: bytes, rank: int, world: int, max_queries: int):
+        self._L, self._m = lib(), matcher       # the matcher (its stream) must outlive this object
+        self._h = vp()
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(self._L.orbfe_knn2_sharded_create(matcher._h, idb, rank, world, max_queries, C.byref(self._h)))
+
+    def run(self, q_ptr, nq, shard_ptr, n_shard, idx_base, bd_ptr, bi_ptr, sd_ptr, sync=True):
+        check(self._L.orbfe_knn2_sharded_run(self._h, vp(q_ptr), nq, vp(shard_ptr), n_shard, idx_base, vp(bd_ptr), vp(bi_ptr),
+                                             vp(sd_ptr), 1 if sync else 0))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            self._L.orbfe_knn2_sharded_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 AREA_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),

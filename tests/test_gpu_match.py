@@ -123,6 +123,55 @@ def test_knn2_full_size_properties():
         assert bd[i] == d[order[0]] and bi[i] == order[0] and sd[i] == d[order[1]]
 
 
+def test_knn2_full_database_one_gpu():
+    """The bench's single-GPU workload (2000 queries x 1 M descriptors: other chunk / group counts than the 125 000 shard):
+    size-independent properties over all queries + 16 queries verified by a numpy scan of the whole database, and the
+    no-alloc entry point on the same input."""
+    torch = pytest.importorskip("torch")
+    db = synth.random_descriptors(1_000_000, 7000)
+    q = synth.planted_queries(db, 2000, 7001, planted_frac=0.1)
+    m = capi.ORBmatcher()
+    bd, bi, sd = _knn2(m, q, db)
+    assert (bd <= sd).all() and (bi >= 0).all() and (bi < len(db)).all()
+    assert np.array_equal(np.unpackbits(q ^ db[bi], axis=1).sum(1), bd)
+    assert (bd[::10] <= 60).all()                                  # the planted rows (every tenth query) found a near duplicate
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for i in range(0, 2000, 125):
+        d = np.zeros(len(db), np.int32)
+        for c0 in range(0, len(db), 250000):
+            d[c0:c0 + 250000] = pop[q[i][None, :] ^ db[c0:c0 + 250000]].sum(1)
+        first = int(np.argmin(d))                                  # first minimum = lowest index among equals
+        assert bd[i] == d[first] and bi[i] == first
+        d[first] = 1 << 20
+        assert sd[i] == d.min()
+    dq, dr = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
+    out = [torch.zeros(len(q), dtype=torch.int32, device="cuda") for _ in range(3)]
+    m.knn2_noalloc_device(dq.data_ptr(), len(q), dr.data_ptr(), len(db), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+    for a, b in zip(out, (bd, bi, sd)):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+def test_knn2_sharded_rccl_one_rank():
+    """orbfe_knn2_sharded_* (RCCL bound at run time inside liborbfe: ncclBroadcast of the queries, local scan, ncclAllGather
+    of the per-shard triples, fold on the device) with a communicator of one rank -- all this box has GPUs for -- equals the
+    plain call; ranks > 1 are covered on the CPU by tests/test_distributed_cpu.py (merge) and need an 8-GPU node to run."""
+    torch = pytest.importorskip("torch")
+    db = synth.random_descriptors(40000, 91)
+    q = synth.planted_queries(db, 700, 92, planted_frac=0.3)
+    m = capi.ORBmatcher()
+    want = _knn2(m, q, db, idx_base=5000)
+    sh = capi.ShardedKnn2(m, capi.sharded_unique_id(), 0, 1, 1024)
+    dq, dr = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
+    for nq in (700, 130):                                          # a second, smaller batch through the same buffers
+        out = [torch.full((nq,), -3, dtype=torch.int32, device="cuda") for _ in range(3)]
+        sh.run(dq.data_ptr(), nq, dr.data_ptr(), len(db), 5000, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+        for a, b in zip(out, want):
+            assert np.array_equal(a.cpu().numpy(), b[:nq])
+    with pytest.raises(capi.OrbfeError):
+        sh.run(dq.data_ptr(), 2000, dr.data_ptr(), len(db), 0, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+    sh.close()
+
+
 def test_csr_matches_oracle():
     rng = np.random.default_rng(5)
     r = synth.random_descriptors(3000, 9)
