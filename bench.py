@@ -3,9 +3,12 @@
 
 Metric (BASELINE.json): ORB extract frames/sec @1241x376, 2000 keypoints, 8 levels; plus Hamming matches/sec.
 
-A "step" is one pass of ORBextractor::operator() over one batch of synthetic KITTI-sized frames that are already resident
-in HBM (orbfe_extract_batch through the C-ABI), keypoints and descriptors left in HBM.  Every rank processes its own
-batch (independent frames: no data-path collective, weak scaling); `value` = frames of all ranks / max-over-ranks time.
+A "step" is one pass of ORBextractor::operator() over BASELINE.json configs[3]: the 4541 synthetic KITTI-sized frames of a
+KITTI-00-length sequence, already resident in HBM, split over the ranks in contiguous blocks of ceil(4541 / G) frames
+ and run through orbfe_extract_batch (the C-ABI) in launches of --batch frames; keypoints and
+descriptors are left in HBM.  Independent frames: no data-path collective; the total work is fixed, so the scaling is
+"strong"; `value` = 4541 x steps / max-over-ranks time.  (--total-frames 0 gives the round-1 weak-scaling step: --batch
+frames per rank and step.)
 
 Extra objects in the JSON line:
   roofline     -- the dominant kernel (FAST): algorithmic bytes per launch / its average duration, measured live with HIP
@@ -13,7 +16,7 @@ Extra objects in the JSON line:
   cpu_baseline -- the CPU oracle (a port of the reference's path: the reference itself needs OpenCV and cannot be built
                   here) timed on the host cores of this box on a bounded sample of the same frames (rank 0, N=1 only).
   hamming      -- brute-force kNN-2 of 2000 queries against a 1M-descriptor database sharded over the ranks
-                  (BASELINE.json config 5), per-shard results gathered with RCCL and merged.
+                  (BASELINE.json config 5): orbfe_knn2_sharded_run -- RCCL broadcast / all-gather and the fold inside liborbfe.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 the driver uses torch.distributed.run.
 """
@@ -48,9 +51,49 @@ def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
     reps = int(max(1, min(1000, budget_s / per_pass)))
     t, kps = O.time_extract(frames, NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, threads, reps=reps)
     n = len(frames) * reps
-    return {"value": round(n / t, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+    # per-frame wall clock on one core, the way the reference's drivers time a frame (steady_clock around the call, then
+    # median and mean over the sequence: Examples/Stereo/stereo_kitti.cc:80-97, :113-122)
+    ex = O.OracleExtractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH)
+    per_frame = []
+    for rep in range(2):
+        for f in frames:
+            t0 = time.perf_counter()
+            ex.extract(np.ascontiguousarray(f))
+            per_frame.append(time.perf_counter() - t0)
+    per_frame = np.array(per_frame[len(frames):])       # second pass: buffers warm
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n / t, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "per_frame_ms_one_core": {"median": round(float(np.median(per_frame)) * 1e3, 3), "mean": round(float(per_frame.mean()) * 1e3, 3),
+                                      "frames": len(per_frame)},
             "sample": f"{n} extractions ({len(frames)} distinct 1241x376 frames x {reps}) in {t:.1f} s, one frame per thread, "
                       f"oracle built -O3 -march=x86-64-v3 -ffp-contract=off; {kps / n:.0f} keypoints/frame"}
+
+
+def csrc_hash() -> str:
+    """sha256 over the sources of liborbfe.so in name order (the same rule as tools/pmc_latest.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(p for p in (ROOT / "orb_slam2_amd" / "csrc").iterdir() if p.suffix in (".h", ".hip", ".inc")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def latest_pmc():
+    """profiles/latest_pmc.json (tools/pmc_passes.sh + tools/pmc_latest.py): counter values per launch of each kernel and the
+    hash of the sources they were taken from; stale = the tree has other kernel sources than the profiled ones."""
+    f = ROOT / "profiles" / "latest_pmc.json"
+    if not f.exists():
+        return None, True
+    doc = json.loads(f.read_text())
+    return doc, doc.get("csrc_sha256") != csrc_hash()
 
 
 def other_configs(local_rank, dev):
@@ -99,7 +142,21 @@ def other_configs(local_rank, dev):
                 "keypoints_per_frame": round(float(cnt.float().mean().item()), 1)}
 
     out["tum_640x480_1000kp"] = batch_fps(640, 480, 1000, 256)
-    out["euroc_752x480_1000kp"] = batch_fps(752, 480, 1000, 256)
+    out["euroc_752x480_1200kp"] = batch_fps(752, 480, 1200, 256)       # Examples/Stereo/EuRoC.yaml:88
+    # BASELINE.json configs[1] through the C++ drop-in (include/ORBextractor.h + adapters/ORBextractor_orbfe.cc): wall clock
+    # around ORBextractor::operator() on a host image, with and without the mvImagePyramid mirror
+    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    if exe.exists():
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            raw = Path(td) / "tum.raw"
+            raw.write_bytes(np.ascontiguousarray(synth.frame_sequence(1, 640, 480, first=900)[0]).tobytes())
+            r = subprocess.run([str(exe), "latency", str(raw), "640", "480", "1000", "200"], capture_output=True, text=True, timeout=120)
+        try:
+            out["tum_640x480_1000kp"]["cpp_adapter_operator_call"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            out["tum_640x480_1000kp"]["cpp_adapter_operator_call"] = {"error": (r.stdout + r.stderr)[-300:]}
 
     # KITTI stereo pair: left + right extraction as one 2-frame batch, then the row-band Hamming search on the device
     W, H, nfeat = 1241, 376, NFEATURES
@@ -273,8 +330,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512,
-                    help="frames per step and rank (512 ~ one GPU's share of the 4541 KITTI-00 frames on 8 GPUs)")
+    ap.add_argument("--batch", type=int, default=512, help="frames per launch (orbfe_extract_batch call)")
+    ap.add_argument("--total-frames", type=int, default=4541,
+                    help="frames per step over ALL ranks, split in contiguous blocks of ceil(total / G) (BASELINE.json configs[3], "
+                         "strong scaling); 0: --batch frames per rank and step (weak scaling)")
     ap.add_argument("--handles", type=int, default=1,
                     help="extractor handles (one HIP stream each) the step's frames are split over; the reference itself "
                          "runs two extractor objects concurrently (src/Frame.cc:78-81)")
@@ -315,29 +374,43 @@ def main():
         torch.cuda.synchronize()
 
     # ---- synthetic frames, resident in HBM before anything is timed
-    B = args.batch
+    strong = args.total_frames > 0
+    if strong:
+        block = -(-args.total_frames // world)                       # contiguous blocks of ceil(total / G) frames
+        f_first = min(rank * block, args.total_frames)
+        B = max(min(block, args.total_frames - f_first), 0)          # this rank's frames per step
+    else:
+        f_first, B = rank * args.batch, args.batch
+    launch = max(1, min(args.batch, max(B, 1)))                      # frames per orbfe_extract_batch call
     stride = (W + 63) // 64 * 64
-    uniq = synth.frame_sequence(N_UNIQUE, W, H, first=rank * N_UNIQUE)
-    host = np.zeros((B, H, stride), np.uint8)
-    for i in range(B):
-        host[i, :, :W] = uniq[i % N_UNIQUE]
-    frames = torch.from_numpy(host).to(dev)
+    uniq = synth.frame_sequence(N_UNIQUE, W, H, first=0)
+    uniq_dev = torch.zeros((N_UNIQUE, H, stride), dtype=torch.uint8)
+    uniq_dev[:, :, :W] = torch.from_numpy(np.ascontiguousarray(uniq))
+    uniq_dev = uniq_dev.to(dev)
+    # frame k of the sequence is synthetic frame k mod 16 (tiled on the device: 4541 x 481 280 B = 2.2 GB resident)
+    frames = uniq_dev[(torch.arange(max(B, 1), device=dev) + f_first) % N_UNIQUE].contiguous()
+    B = max(B, 1) if not strong else B
+    if B == 0:
+        frames = frames[:0]
     cap = NFEATURES + 4 * NLEVELS + 32
-    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    nb = max(B, 1)
+    kps = torch.zeros((nb, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((nb, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
     # The step's B frames are split over `handles` extractor objects.  Each owns a HIP stream, so the latency-bound
     # stages of one half (pyramid chain, quadtree) run under the VALU-bound stages of the other (FAST, blur, describe).
-    nh = max(1, min(args.handles, B))
+    nh = max(1, min(args.handles, nb))
     bounds = [B * k // nh for k in range(nh + 1)]
     exs = [capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank) for _ in range(nh)]
 
     def step():
-        # asynchronous on the library's streams: the K steps queue back to back, as an offline extraction job would
+        # asynchronous on the library's streams: the launches of all K steps queue back to back, as an offline extraction
+        # job would; every frame of the rank's block is extracted once per step, its outputs in its own slot
         for k, ex in enumerate(exs):
-            f0, f1 = bounds[k], bounds[k + 1]
-            ex.extract_batch_device(frames[f0].data_ptr(), f1 - f0, W, H, stride, stride * H, kps[f0].data_ptr(),
-                                    desc[f0].data_ptr(), cnt[f0:].data_ptr(), cap, sync=False)
+            for f0 in range(bounds[k], bounds[k + 1], launch):
+                n = min(launch, bounds[k + 1] - f0)
+                ex.extract_batch_device(frames[f0].data_ptr(), n, W, H, stride, stride * H, kps[f0].data_ptr(),
+                                        desc[f0].data_ptr(), cnt[f0:].data_ptr(), cap, sync=False)
 
     def sync_all():
         for ex in exs:
@@ -374,9 +447,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    total_frames = B * args.steps * world
+    total_frames = (args.total_frames if strong else B * world) * args.steps
     fps = total_frames / dt
-    kp_per_frame = float(cnt.float().mean().item())
+    kp_per_frame = float(cnt.float().mean().item()) if B else 0.0
 
     # ---- roofline of the dominant kernel (FAST): algorithmic bytes = level pixels read + 8 B per candidate written
     fast_ms = prof["stage_ms"]["fast"] / max(prof["stage_launches"]["fast"], 1)
@@ -384,27 +457,34 @@ def main():
     frames_per_launch = prof["frames"] / max(prof["stage_launches"]["fast"], 1)
     fast_bytes = frames_per_launch * (LEVEL_PIXELS + 8 * cand_per_frame)
     achieved = fast_bytes / (fast_ms * 1e-3) / 1e9 if fast_ms > 0 else 0.0
-    # traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at 512 frames per launch
-    # (profiles/r1j_pmc_summary.txt): 2 x 456.3 MB fetched (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md) +
-    # 53.6 MB written = 1.93 MB per frame; scaled to the frames one launch of this run processes.
-    traffic = int(frames_per_launch * (2 * 456320.1 + 53624.5) * 1024 / 512)
+    # traffic and instruction count: the rocprofv3 --pmc passes recorded in profiles/latest_pmc.json (tools/pmc_passes.sh,
+    # tools/pmc_latest.py), per frame, scaled to the frames one launch of this run processes.  FETCH_SIZE x 2: gfx950 tallies
+    # 128-byte fabric requests at 64 bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact; both in KB.
+    pmc, pmc_stale = latest_pmc()
+    fk = (pmc or {}).get("kernels", {}).get("fast_cells_kernel", {})
+    pmc_frames = max((pmc or {}).get("frames_per_launch", 1), 1)
+    traffic = None
+    if "FETCH_SIZE" in fk and "WRITE_SIZE" in fk:
+        traffic = int(frames_per_launch * (2 * fk["FETCH_SIZE"] + fk["WRITE_SIZE"]) * 1024 / pmc_frames)
     roofline = {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "ms_per_launch": round(fast_ms, 4), "algorithmic_bytes_per_launch": int(fast_bytes),
-                "frames_per_launch": frames_per_launch,
-                "note": "FAST is integer-VALU-bound, not HBM-bound: ~200 VALU instructions per wave and pixel row (156 of them the "
-                        "packed min/max of the arc-score network and the 3x3 suppression, at the measured 4.15 cycles), SQ_INSTS_VALU says 97 % "
-                        "issue utilisation (profiles/r1j_pmc_summary.txt); ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
+                "frames_per_launch": round(frames_per_launch, 2),
+                "pmc": {"file": "profiles/latest_pmc.json", "stale": bool(pmc_stale),
+                        "csrc_sha256": (pmc or {}).get("csrc_sha256", "")[:16]},
+                "note": "FAST is integer-VALU-bound, not HBM-bound (valu_issue below: SQ_INSTS_VALU x 4.15 cycles against the kernel's "
+                        "SIMD cycles); ms_per_launch is the HIP-event time around the kernel inside the timed region (with "
                         "--handles > 1 the other handle's kernels run concurrently and inflate it); stage_ms_per_step "
                         "comes from 5 extra un-timed steps with events around every stage",
                 "stage_ms_per_step": stages}
-    # the resource FAST is actually bound by: VALU issue slots.  SQ_INSTS_VALU of this kernel is 618.2 M wave instructions per
-    # 512-frame launch of this workload (profiles/r1j_pmc_summary.txt; the count depends on the frames, not on the run), a
-    # packed-integer instruction occupies a SIMD for 4.15 cycles (profiles/r1_valu_rates_ubench.txt), 1024 SIMDs at 2.4 GHz.
-    valu_instr = 618.2e6 / 512 * frames_per_launch
-    roofline["valu_issue"] = {"wave_instructions_per_launch": int(valu_instr), "cycles_per_instruction": 4.15,
-                              "frac": round(valu_instr * 4.15 / (1024 * 2.4e9 * fast_ms * 1e-3), 4) if fast_ms > 0 else None,
-                              "note": "instruction count from the PMC pass in profiles/, duration live; 2.4 GHz nominal clock"}
+    # the resource FAST is actually bound by: VALU issue slots.  SQ_INSTS_VALU per frame from the same PMC file (the count
+    # depends on the frames, not on the run), a packed-integer instruction occupies a SIMD for 4.15 cycles
+    # (profiles/r1_valu_rates_ubench.txt), 1024 SIMDs at 2.4 GHz.
+    if "SQ_INSTS_VALU" in fk:
+        valu_instr = fk["SQ_INSTS_VALU"] / pmc_frames * frames_per_launch
+        roofline["valu_issue"] = {"wave_instructions_per_launch": int(valu_instr), "cycles_per_instruction": 4.15,
+                                  "frac": round(valu_instr * 4.15 / (1024 * 2.4e9 * fast_ms * 1e-3), 4) if fast_ms > 0 else None,
+                                  "note": "instruction count from profiles/latest_pmc.json, duration live; 2.4 GHz nominal clock"}
     # every dense stage against HBM (algorithmic bytes per frame, each datum moved once), from the
     # un-timed per-stage pass; the descriptor stage by the unique bytes it gathers (749 B disc + <= 1369 B window + 60 B out)
     spf = sum(p["frames"] for p in stage_profs) / 5
@@ -425,21 +505,36 @@ def main():
         q = torch.from_numpy(q_host).to(dev)
         res = torch.zeros((3, NQ), dtype=torch.int32, device=dev)
         m = capi.ORBmatcher(device=local_rank)
-        gathered = torch.zeros((world * 3, NQ), dtype=torch.int32, device=cdev) if world > 1 else None
+        # N > 1: the exchange runs inside liborbfe (orbfe_knn2_sharded_run: ncclBroadcast of the queries, local scan,
+        # ncclAllGather of the per-shard triples, fold kernel); torch.distributed only ships the 128-byte RCCL id.
+        # ORBFE_BENCH_BACKEND=gloo (rehearsal on fewer GPUs than ranks, where RCCL cannot form a communicator) keeps the
+        # round-1 path: host-side collectives + orbfe_merge_knn2.
+        sharded = None
+        gathered = None
+        if world > 1 and backend == "nccl":
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.sharded_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            torch.cuda.synchronize()
+            sharded = capi.ShardedKnn2(m, bytes(idt.cpu().numpy().tobytes()), rank, world, NQ)
+        elif world > 1:
+            gathered = torch.zeros((world * 3, NQ), dtype=torch.int32, device=cdev)
 
         def hstep():
+            if sharded is not None:
+                sharded.run(q.data_ptr(), NQ, db.data_ptr(), shard, rank * shard, res[0].data_ptr(), res[1].data_ptr(),
+                            res[2].data_ptr(), sync=True)
+                return None
             if world > 1:
-                if cdev is dev:
-                    dist.broadcast(q, src=0)
-                else:
-                    qc = q.cpu()
-                    dist.broadcast(qc, src=0)
-                    q.copy_(qc)
+                qc = q.cpu()
+                dist.broadcast(qc, src=0)
+                q.copy_(qc)
                 torch.cuda.synchronize()      # the matcher runs on its own non-blocking stream: order it after the broadcast
             m.knn2_device(q.data_ptr(), NQ, db.data_ptr(), shard, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
                           idx_base=rank * shard, sync=True)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, res if cdev is dev else res.cpu())
+                dist.all_gather_into_tensor(gathered, res.cpu())
                 g = gathered.view(world, 3, NQ).cpu().numpy()
                 return capi.merge_knn2(g[:, 0], g[:, 1], g[:, 2])
             return None
@@ -464,6 +559,8 @@ def main():
         peak_pairs = world * 1024 * 2.4e9 / 4 / 16 * 64
         hamming = {"metric": "hamming_pair_distances_per_sec", "value": round(pairs / hdt, 1), "ms_per_query_batch": round(hdt / hsteps * 1e3, 3),
                    "queries": NQ, "database": shard * world, "shards": world,
+                   "exchange": "none (one shard)" if world == 1 else ("RCCL inside liborbfe (orbfe_knn2_sharded_run)" if sharded is not None
+                                                                      else "host collectives (rehearsal backend) + orbfe_merge_knn2"),
                    "valu": {"achieved_Tpairs": round(pairs / hdt / 1e12, 3), "peak_Tpairs": round(peak_pairs / 1e12, 3),
                             "frac": round(pairs / hdt / peak_pairs, 4), "valu_instructions_per_pair": 16.75,
                             "note": "8 v_xor + 8 v_bcnt_u32_b32 (accumulating) + v_min3/v_min/v_cmp per 4 references; the best/second "
@@ -495,10 +592,15 @@ def main():
         out = {
             "metric": "orb_extract_frames_per_sec_1241x376_2000kp_8lvl", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "batched ORB extraction, 1241x376 KITTI-size frames resident in HBM, 2000 features, "
-                                   "8 levels, scale 1.2, FAST 20/7 (BASELINE.json configs[0] shape, configs[3] batching)",
-                       "frames_per_step_per_gpu": B, "handles": nh, "keypoints_per_frame": round(kp_per_frame, 1),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[3]: batched offline ORB extraction of 4541 synthetic 1241x376 frames (KITTI-00 "
+                                    "length) resident in HBM, 2000 features, 8 levels, scale 1.2, FAST 20/7, contiguous blocks of "
+                                    "ceil(4541 / G) frames per GPU" if strong and args.total_frames == 4541 else
+                                    "batched ORB extraction, 1241x376 KITTI-size frames resident in HBM, 2000 features, 8 levels, "
+                                    "scale 1.2, FAST 20/7"),
+                       "frames_per_step": args.total_frames if strong else B * world, "frames_per_step_rank0": B,
+                       "frames_per_launch": launch, "handles": nh, "keypoints_per_frame": round(kp_per_frame, 1),
                        "parallelism": f"frames sharded over {world} gpu(s), no collective"},
             "roofline": roofline, "cpu_baseline": cpu, "hamming": hamming, "other_configs": extras,
         }
