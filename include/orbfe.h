@@ -123,6 +123,12 @@ int orbfe_pyramid_mirror(orbfe_extractor *e, int frame, uint8_t *const *dst, con
  * Returns the number of bytes the stage holds in *bytes; copies min(*bytes, dst_bytes). */
 int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *dst, size_t dst_bytes, size_t *bytes);
 
+/* The rotation computeOrbDescriptor derives from a keypoint angle (src/ORBextractor.cc:111-113: angle * factorPI in
+ * float, then cosf / sinf), evaluated alone on the device by the function the descriptor kernel uses: cos_sin[2*i] = a,
+ * cos_sin[2*i+1] = b for angles_deg[i].  Host pointers; synchronous.  For the known-answer test over the angles where a
+ * faster device routine used to differ from libm (tests/golden/sincos_census.json). */
+int orbfe_debug_rotation(orbfe_extractor *e, const float *angles_deg, int n, float *cos_sin);
+
 /* Per-stage device timing of the extractor, taken with HIP events recorded on the handle's stream around each
  * stage's kernel launches inside orbfe_extract / orbfe_extract_batch (no counterpart in the reference, whose only
  * timing is the wall clock around TrackStereo in Examples/Stereo/stereo_kitti.cc:80-97).  Enabling resets the sums.

@@ -33,6 +33,7 @@ EXPORTS = [
     "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence", "orbfe_match_knn2_noalloc",
     "orbfe_knn2_sharded_unique_id", "orbfe_knn2_sharded_create", "orbfe_knn2_sharded_run", "orbfe_knn2_sharded_destroy",
     "orbfe_frame_grid_update", "orbfe_pyramid_mirror", "orbfe_bow_transform_host", "orbfe_stereo_rowband_host", "orbfe_stereo_match_host",
+    "orbfe_debug_rotation",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -90,6 +91,7 @@ def lib():
     L.orbfe_extract_sequence.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, vp, vp, C.c_int, C.c_int]
     L.orbfe_pyramid_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, i32p, i32p]
     L.orbfe_debug_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orbfe_debug_rotation.argtypes = [vp, vp, C.c_int, vp]
     L.orbfe_hamming.argtypes = [vp, vp]
     L.orbfe_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.orbfe_matcher_destroy.argtypes = [vp]
@@ -272,6 +274,13 @@ class ORBextractor:
             check(self._L.orbfe_pyramid_level(self._h, frame, level, None, 0, C.byref(w), C.byref(h)))
             return raw.reshape(h.value, w.value)
         return raw.view(np.float32).reshape(-1, 3 if what == 2 else 4)
+
+    def debug_rotation(self, angles_deg):
+        """(cos, sin) pairs the descriptor kernel derives from float keypoint angles in degrees."""
+        a = np.ascontiguousarray(angles_deg, np.float32)
+        out = np.zeros((a.size, 2), np.float32)
+        check(self._L.orbfe_debug_rotation(self._h, _np_ptr(a), a.size, _np_ptr(out)))
+        return out
 
 
 class ORBmatcher:

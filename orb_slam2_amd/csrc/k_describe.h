@@ -14,9 +14,9 @@
 //      (5 per lane); per dword two v_dot4_u32_u8 against a mask / weight pair from an LDS table indexed by the patch's
 //      alignment (cx-15)&3 give sum(I) and sum((u+18) I) over the bytes inside the disc; m01 += v*sum(I); a DPP
 //      reduction folds the 64 lanes and the totals land in lane k of (m10, m01);
-//   2. lanes 0..15: angle = cv::fastAtan2's polynomial in float32 with every operation individually rounded, a = cos and
-//      b = sin taken in double and rounded to float (the reference calls libm cosf/sinf); the KeyPoint
-//      records are written here;
+//   2. lanes 0..15: angle = cv::fastAtan2's polynomial in float32 with every operation individually rounded, a = cosf and
+//      b = sinf by glibc's algorithm (sincosf_glibc below: the reference calls libm cosf/sinf, and the device's floats
+//      equal glibc 2.35's for every float angle, DESIGN.md section 2 pin 3); the KeyPoint records are written here;
 //   3. descriptor, one keypoint at a time: the 37 x 37 window of the blurred level that the rotated taps can reach
 //      (|tap| <= round(18.38) = 18) is staged into LDS with 6 row-coalesced dword loads per lane, then lane i evaluates
 //      test pairs 4i..4i+3: tap offsets are cvRound(px*b + py*a), cvRound(px*a - py*b) with un-fused float
@@ -76,37 +76,53 @@ __device__ __forceinline__ int wave_sum_uniform(int v) {
            __builtin_amdgcn_readlane(v, 48);
 }
 
-// sin and cos of x in [0, 2*pi] in double, good to ~1e-15 absolute: quadrant reduction with a two-term pi/2, then Taylor
-// polynomials on |r| <= pi/4 (remainders (pi/4)^17/17! and (pi/4)^16/16! are below 1e-16).  About 30 double operations
-// instead of the ~170 of the general-purpose library routine; every operation is an explicit fma/mul/add.
-__device__ __forceinline__ void sincos_0_2pi(double x, double *s, double *c) {
-    const double twoOverPi = 0.63661977236758134308, pio2Hi = 1.57079632679489655800e+00, pio2Lo = 6.12323399573676603587e-17;
-    const double qd = __builtin_rint(x * twoOverPi);
-    const int q = (int)qd;
-    double r = __builtin_fma(-qd, pio2Hi, x);
-    r = __builtin_fma(-qd, pio2Lo, r);
-    const double z = r * r;
-    double ps = -7.6471637318198164759e-13;                // -1/15!
-    ps = __builtin_fma(ps, z, 1.6059043836821614599e-10);  //  1/13!
-    ps = __builtin_fma(ps, z, -2.5052108385441718775e-08); // -1/11!
-    ps = __builtin_fma(ps, z, 2.7557319223985890653e-06);  //  1/9!
-    ps = __builtin_fma(ps, z, -1.9841269841269841270e-04); // -1/7!
-    ps = __builtin_fma(ps, z, 8.3333333333333333333e-03);  //  1/5!
-    ps = __builtin_fma(ps, z, -1.6666666666666666667e-01); // -1/3!
-    const double sr = __builtin_fma(ps * z, r, r);
-    double pc = 4.7794773323873852974e-14;                 //  1/16!
-    pc = __builtin_fma(pc, z, -1.1470745597729724714e-11); // -1/14!
-    pc = __builtin_fma(pc, z, 2.0876756987868098979e-09);  //  1/12!
-    pc = __builtin_fma(pc, z, -2.7557319223985890653e-07); // -1/10!
-    pc = __builtin_fma(pc, z, 2.4801587301587301587e-05);  //  1/8!
-    pc = __builtin_fma(pc, z, -1.3888888888888888889e-03); // -1/6!
-    pc = __builtin_fma(pc, z, 4.1666666666666666667e-02);  //  1/4!
-    pc = __builtin_fma(pc, z, -0.5);
-    const double cr = __builtin_fma(pc, z, 1.0);
-    // rotate by the quadrant
-    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
-    *s = (q & 2) ? -s0 : s0;
-    *c = ((q + 1) & 2) ? -c0 : c0;
+// cosf(y) and sinf(y) as glibc 2.35 computes them (sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c, s_cosf.c: the reference
+// calls them at src/ORBextractor.cc:112-113), for 0 <= y < 2^23: reduction n = round(y * 2/pi) through the 2^24-scaled
+// product, x = y - n * (pi/2) in double, then the degree-7 odd / degree-8 even polynomials in double and ONE rounding to
+// float.  The quadrant sign enters glibc's polynomials through x*sign and a table with negated cosine coefficients; both
+// are exact negations of the value computed here, so they are applied to the result.  tools/sincos_census.c checks the host
+// mirror of this routine against libm over every float angle in [0, 360): 0 of 1 135 869 952 differ (with and without
+// fused multiply-adds: the contraction glibc's build may apply does not change any rounded float on this domain).
+__device__ __forceinline__ void sincosf_glibc(float y, float *sOut, float *cOut) {
+    const double hpiInv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double xd = (double)y;
+    const int n = ((int)(xd * hpiInv) + 0x800000) >> 24;      // 0 for y < pi/4: glibc's no-reduction branch is the same code
+    const double x = __builtin_fma(-(double)n, hpi, xd);
+    const double x2 = x * x;
+    // sine polynomial
+    const double x3 = x * x2;
+    const double sa = __builtin_fma(x2, s3, s2);
+    const double x7 = x3 * x2;
+    const double sb = __builtin_fma(x3, s1, x);
+    float S = (float)__builtin_fma(x7, sa, sb);
+    // cosine polynomial
+    const double x4 = x2 * x2;
+    const double ca = __builtin_fma(x2, c4, c3);
+    const double cb = __builtin_fma(x2, c2, c1);
+    const double x6 = x4 * x2;
+    const double cc = __builtin_fma(x2, cb, c0);
+    float C = (float)__builtin_fma(x6, ca, cc);
+    // |y| < 2^-12: glibc returns y and 1.0f without evaluating
+    const bool tiny = ((__float_as_uint(y) >> 20) & 0x7ff) < ((__float_as_uint(0x1p-12f) >> 20) & 0x7ff);
+    S = tiny ? y : S;
+    C = tiny ? 1.0f : C;
+    const float sq = (n & 1) ? C : S, cq = (n & 1) ? S : C;
+    *sOut = (n & 2) ? -sq : sq;
+    *cOut = ((n + 1) & 2) ? -cq : cq;
+}
+
+// The rotation the descriptor kernel derives from a keypoint angle, alone: out[i] = (cos, sin) of angleDeg[i] * factorPI,
+// computed by the same device function (orbfe_debug_rotation; the census angles of tests/golden/sincos_census.json).
+__global__ void __launch_bounds__(256) debug_rotation_kernel(const float *angleDeg, int n, float2 *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float s, c;
+    sincosf_glibc(__fmul_rn(angleDeg[i], factorPI), &s, &c);
+    out[i] = make_float2(c, s);
 }
 
 constexpr int kDescKpPerWave = 8;
@@ -286,9 +302,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(DescribeArgs a) {
     const float angle = fast_atan2_deg((float)m01V, (float)m10V);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
-    double sd, cd;
-    sincos_0_2pi((double)ang, &sd, &cd);
-    const float caV = (float)cd, sbV = (float)sd;
+    float caV, sbV;
+    sincosf_glibc(ang, &sbV, &caV);
     if (valid && lane < kDescKpPerWave) {
         KeyPointOut o;
         o.x = (float)cxV;

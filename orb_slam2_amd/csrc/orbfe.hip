@@ -1186,6 +1186,29 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
     return fail(ORBFE_ERR_ARG, "unknown stage");
 }
 
+int orbfe_debug_rotation(orbfe_extractor *e, const float *angles_deg, int n, float *cos_sin) {
+    if (!e || n < 0 || (n && (!angles_deg || !cos_sin))) return fail(ORBFE_ERR_ARG, "bad argument");
+    if (n == 0) return ORBFE_OK;
+    HIPCHK(hipSetDevice(e->device));
+    DevBuf in, out;
+    HIPCHK(in.ensure((size_t)n * sizeof(float)));
+    if (hipError_t err = out.ensure((size_t)n * sizeof(float2))) {
+        in.release();
+        return fail(ORBFE_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(err));
+    }
+    hipError_t err = hipMemcpyAsync(in.p, angles_deg, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) {
+        debug_rotation_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>((const float *)in.p, n, (float2 *)out.p);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(cos_sin, out.p, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    in.release();
+    out.release();
+    if (err != hipSuccess) return fail(ORBFE_ERR_DEVICE, std::string("orbfe_debug_rotation: ") + hipGetErrorString(err));
+    return ORBFE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ matcher ----------
 int orbfe_hamming(const uint8_t *a32, const uint8_t *b32) {
     // ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663): popcount of the XOR of 8 dwords

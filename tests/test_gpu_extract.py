@@ -342,3 +342,83 @@ def test_extract_sequence_host_to_host(pinned):
             assert np.array_equal(desc.numpy()[f, :len(kr)], dr), (w, f)
     with pytest.raises(capi.OrbfeError):
         g.extract_sequence_host(t.data_ptr(), n, w, h, stride + 4, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap)
+
+
+def _libm_cos_sin(ang_f32):
+    """(cosf, sinf) of this host's libm -- what the reference's computeOrbDescriptor calls (src/ORBextractor.cc:112-113)."""
+    import ctypes
+    import ctypes.util
+    m = ctypes.CDLL(ctypes.util.find_library("m"))
+    for f in (m.cosf, m.sinf):
+        f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float]
+    return np.array([(m.cosf(float(a)), m.sinf(float(a))) for a in ang_f32], np.float32)
+
+
+def test_rotation_known_answers():
+    """The descriptor rotation (a, b) = (cosf, sinf)(angle * factorPI) on the device against libm, bit for bit:
+    (1) every angle of tests/golden/sincos_census.json -- the 96 angles where round 1's faster routine moved a pattern tap
+    and a sample of 1450 of the 1 484 894 angles where it produced a different float (tools/sincos_census.c, all
+    1 135 869 952 floats in [0, 360) enumerated; the routine in use now differs for none of them on the host mirror);
+    (2) edge angles and 200 000 random floats of [0, 360) against this host's libm directly."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincos_census.json")))
+    assert gold["stride"] == 1 and gold["angles_evaluated"] == gold["floats_in_0_360"] == 1135869952
+    assert gold["glibc"] == {"angles_where_cos_or_sin_differs": 0, "cos_differs": 0, "sin_differs": 0}
+    rows = np.array(gold["tap_moving_angles"] + gold["sample_of_differing_angles"], np.uint32)
+    assert len(gold["tap_moving_angles"]) == gold["taylor"]["angles_where_a_tap_moves"] == 96
+    g = capi.ORBextractor(1000, 1.2, 8, 20, 7)
+    got = g.debug_rotation(rows[:, 0].copy().view(np.float32))
+    assert np.array_equal(got.view(np.uint32), rows[:, 1:3]), "device rotation differs from the census' libm values"
+
+    rng = np.random.default_rng(20240607)
+    edge = np.array([0.0, 1e-30, 1e-6, 0.0139, 0.014, 44.999996, 45.0, 45.000004, 89.99999, 90.0, 90.00001, 135.0, 179.99998, 180.0,
+                     180.00002, 225.0, 269.99997, 270.0, 270.00003, 315.0, 359.99997], np.float32)
+    ang = np.concatenate([edge, rng.integers(0, 1135869952, 200000, dtype=np.uint32).view(np.float32),
+                          rng.uniform(0, 360, 50000).astype(np.float32)])
+    factor_pi = np.float32(3.1415926535897932384626433832795 / np.float32(180.0))
+    want = _libm_cos_sin((ang * factor_pi).astype(np.float32))
+    got = g.debug_rotation(ang)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_extract_sequence_4541_frames():
+    """BASELINE configs[3] at its full length through orbfe_extract_sequence: 4541 KITTI-sized frames in host memory, eight
+    distinct images repeated.  The first period is checked against the oracle frame by frame; every later frame must then
+    reproduce the frame eight before it exactly (count, keypoint bytes, descriptor bytes) -- any cross-frame leak in the
+    chunked, double-buffered pipeline (a ragged last chunk included: 4541 = 70 * 64 + 61) breaks the periodicity."""
+    import hashlib
+    torch = pytest.importorskip("torch")
+    n, w, h, cap, period = 4541, 1241, 376, 2200, 8
+    stride = 1280
+    t = torch.zeros((n, h, stride), dtype=torch.uint8).pin_memory()
+    host = t.numpy()
+    base = [synth.textured_image(w, h, synth.BASE_SEED + 900 + f) for f in range(period)]
+    for f in range(n):
+        host[f, :, :w] = base[f % period]
+    kps = torch.zeros((n, cap, 7), dtype=torch.float32).pin_memory()
+    desc = torch.zeros((n, cap, 32), dtype=torch.uint8).pin_memory()
+    cnt = torch.zeros(n, dtype=torch.int32).pin_memory()
+    g = capi.ORBextractor(2000, 1.2, 8, 20, 7)
+    g.extract_sequence_host(t.data_ptr(), n, w, h, stride, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, chunk=64)
+    c = cnt.numpy()
+    kb = kps.numpy().view(np.uint8).reshape(n, cap, 28)
+    db = desc.numpy()
+    o = O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    for f in range(period):
+        kr, dr = o.extract(base[f])
+        assert int(c[f]) == len(kr), f
+        assert np.array_equal(kb[f, :len(kr)].copy().view(capi.KP_DTYPE).reshape(-1), kr), f
+        assert np.array_equal(db[f, :len(kr)], dr), f
+    assert 1500 < int(c[:period].min()) and int(c.max()) <= cap
+    assert np.array_equal(c, np.tile(c[:period], n // period + 1)[:n]), "keypoint counts are not periodic"
+
+    def sha(f):
+        m = hashlib.sha256()
+        m.update(kb[f, :c[f]].tobytes())
+        m.update(db[f, :c[f]].tobytes())
+        return m.digest()
+
+    first = [sha(f) for f in range(period)]
+    assert len(set(first)) == period
+    bad = [f for f in range(period, n) if sha(f) != first[f % period]]
+    assert not bad, f"{len(bad)} frames differ from their first occurrence, first: {bad[:5]}"

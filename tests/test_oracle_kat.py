@@ -6,6 +6,7 @@ known answers of SURVEY.md section 8c plus independent numpy restatements of the
 """
 import hashlib
 import math
+import os
 
 import numpy as np
 import pytest
@@ -772,3 +773,34 @@ def test_three_maxima_and_rotation_filter():
     # negative differences wrap by +360: -10 -> 350 -> bin 12; unmatched entries stay out of the histogram
     m, n = O.rotation_filter(np.array([0, 0, 0], np.float32), np.array([10, 10, 0], np.float32), np.array([0, 1, -1]))
     assert n == 2 and m.tolist() == [0, 1, -1]
+
+
+def test_sincos_census_sampled(tmp_path):
+    """tools/sincos_census.c at stride 509 (2.2 M of the 1.136 G float angles; the committed tests/golden/sincos_census.json
+    is the stride-1 run): the host mirror of the device's cos/sin routine equals libm for every angle evaluated, and the
+    golden file's libm values are the ones this host's libm gives."""
+    import ctypes
+    import ctypes.util
+    import json
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sincos_census")
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", os.path.join(root, "tools", "sincos_census.c"), "-o", exe,
+                    "-lm"], check=True)
+    out = json.loads(subprocess.run([exe, "509"], check=True, capture_output=True, text=True).stdout)
+    assert out["angles_evaluated"] == (1135869952 + 508) // 509
+    assert out["glibc"]["angles_where_cos_or_sin_differs"] == 0
+    assert out["taylor"]["angles_where_cos_or_sin_differs"] > 1000      # the census does see the routine it was written for
+
+    gold = json.load(open(os.path.join(root, "tests", "golden", "sincos_census.json")))
+    m = ctypes.CDLL(ctypes.util.find_library("m"))
+    for f in (m.cosf, m.sinf):
+        f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float]
+    factor_pi = np.float32(3.1415926535897932384626433832795 / np.float32(180.0))
+    rows = np.array(gold["tap_moving_angles"] + gold["sample_of_differing_angles"], np.uint32)
+    ang = (rows[:, 0].copy().view(np.float32) * factor_pi).astype(np.float32)
+    want = np.array([(m.cosf(float(a)), m.sinf(float(a))) for a in ang], np.float32).view(np.uint32)
+    assert np.array_equal(want, rows[:, 1:3])
