@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -27,7 +28,7 @@ def _ptr(a, t):
 def lib():
     global _LIB
     if _LIB is None:
-        so = ROOT / "oracle" / "liborb_oracle.so"
+        so = Path(os.environ.get("ORB_ORACLE_LIB", ROOT / "oracle" / "liborb_oracle.so"))   # ORB_ORACLE_LIB: `make asan` build
         if not so.exists():
             subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
         L = C.CDLL(str(so))

@@ -1,5 +1,6 @@
 """The C++ adapter (include/ORBextractor.h + adapters/ORBextractor_orbfe.cc: the reference's class interface on the
 C-ABI), driven like Frame::ExtractORB by tests/cpp/adapter_main, must reproduce the oracle bit for bit."""
+import os
 import subprocess
 from pathlib import Path
 
@@ -11,10 +12,11 @@ from orb_slam2_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
+CPP_BIN = Path(os.environ.get("ORBFE_TEST_BIN_DIR", ROOT / "tests" / "cpp"))   # tools/run_asan.sh points this at tests/cpp/_asan
 
 
 def test_cpp_adapter_matches_oracle(tmp_path):
-    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    exe = CPP_BIN / "adapter_main"
     assert exe.exists(), "build it with make -C orb_slam2_amd/csrc (done by __graft_entry__.build())"
     w, h, nf = 752, 480, 1200
     img = synth.textured_image(w, h, synth.BASE_SEED + 60)
@@ -39,7 +41,7 @@ def test_cpp_adapter_matches_oracle(tmp_path):
 
 def test_cpp_stereo_matcher_matches_oracle(tmp_path):
     """orbfe::StereoMatcher (include/ORBmatcher_orbfe.h) behind two adapter extractors == Frame::ComputeStereoMatches."""
-    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    exe = CPP_BIN / "adapter_main"
     assert exe.exists()
     w, h, nf = 1241, 376, 2000
     bf, b = 386.1448, 0.5371657
@@ -66,7 +68,7 @@ def test_cpp_stereo_matcher_matches_oracle(tmp_path):
 def test_cpp_vocabulary_transform_matches_oracle(tmp_path):
     """orbfe::Vocabulary (include/ORBVocabulary_orbfe.h): loadFromTextFile in the ORBvoc.txt format, then
     transform(descriptors, BowVector, FeatureVector, 4) as Frame::ComputeBoW calls it; doubles bit-exact."""
-    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    exe = CPP_BIN / "adapter_main"
     assert exe.exists()
     k, L, levelsup = 10, 4, 2
     co, ci, nd, wi, w = synth.random_vocabulary(k, L, 4242)
@@ -102,7 +104,7 @@ def test_cpp_projection_search_replays_the_reference_loop(tmp_path):
     """orbfe::ProjectionSearch (include/ORBmatcher_orbfe.h) == ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th)
     (src/ORBmatcher.cc:45-129) run sequentially on the oracle: same association per map point, same nmatches, including
     map points whose best keypoint was taken earlier in the same call (those are searched again on the device)."""
-    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    exe = CPP_BIN / "adapter_main"
     assert exe.exists()
     W, H = 1241, 376
     img = synth.textured_image(W, H, synth.BASE_SEED + 321)
@@ -168,7 +170,7 @@ def test_cpp_projection_search_replays_the_reference_loop(tmp_path):
 def test_cpp_bow_matcher_matches_oracle(tmp_path, max_dist, check_ori):
     """orbfe::BowMatcher::SearchByBoW (include/ORBmatcher_orbfe.h): merge walk over two DBoW2-style FeatureVectors, device
     loops, rotation histogram + ComputeThreeMaxima == the oracle's restatement of src/ORBmatcher.cc:159-288 / :522-655."""
-    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    exe = CPP_BIN / "adapter_main"
     assert exe.exists()
     rng = np.random.default_rng(77 + max_dist)
     n1, n2 = 1800, 2000
@@ -223,7 +225,7 @@ def test_cpp_track_last_frame_replays_the_reference_loop(tmp_path, check_ori):
     """orbfe::ProjectionSearch::searchLastFrame == SearchByProjection(CurrentFrame, LastFrame, th, bMono)
     (src/ORBmatcher.cc:1328-1470) from the window search on, replayed sequentially on the oracle: forward / backward / normal
     level ranges, the right-coordinate gate, unobserved (temporal) points whose keypoint can be overwritten, the histogram."""
-    exe = ROOT / "tests" / "cpp" / "adapter_main"
+    exe = CPP_BIN / "adapter_main"
     assert exe.exists()
     W, H = 1241, 376
     img = synth.textured_image(W, H, synth.BASE_SEED + 654)

@@ -7,6 +7,7 @@ CPU part: the oracle's C++ restatements against independent numpy restatements (
 scanning).  GPU part: the C-ABI entry points (orbfe_search_area_ex, orbfe_search_for_triangulation) and the C++ adapters of
 include/ORBmatcher_orbfe.h (through tests/cpp/adapter_main) against the oracle, association for association.
 """
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -15,6 +16,7 @@ import numpy as np
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+CPP_BIN = Path(os.environ.get("ORBFE_TEST_BIN_DIR", ROOT / "tests" / "cpp"))   # tools/run_asan.sh points this at tests/cpp/_asan
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
@@ -351,7 +353,7 @@ def test_oracle_search_for_triangulation_vs_numpy():
 
 # ------------------------------------------------------------------ GPU: C-ABI and C++ adapters against the oracle ------
 
-EXE = ROOT / "tests" / "cpp" / "adapter_main"
+EXE = CPP_BIN / "adapter_main"
 
 
 def write_side(fh, F, P, occ):

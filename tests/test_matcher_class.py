@@ -11,6 +11,7 @@ from src/ORBmatcher.cc:951-971 / :1081-1096 and src/MapPoint.cc:98-109, :177-215
 """
 import ctypes
 import math
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -19,6 +20,7 @@ import numpy as np
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+CPP_BIN = Path(os.environ.get("ORBFE_TEST_BIN_DIR", ROOT / "tests" / "cpp"))   # tools/run_asan.sh points this at tests/cpp/_asan
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
@@ -27,7 +29,7 @@ from test_guided_search import SF, SIGMA2, INV_SIGMA2, frame, noisy, shared_node
 
 pytestmark = pytest.mark.gpu
 
-EXE = ROOT / "tests" / "cpp" / "matcher_main"
+EXE = CPP_BIN / "matcher_main"
 f32 = np.float32
 
 # camera of KITTI 00-02 (Examples/Stereo/KITTI00-02.yaml:9-16); undistorted bounds as a distorted camera would give them
