@@ -161,6 +161,135 @@ __device__ __forceinline__ void fast_row_pairs(uint32_t raw, uint32_t (&q)[8]) {
     q[7] = ER;
 }
 
+// ---- the end of a tile, shared by the dense and the sparse kernel: `list` holds the wave's survivor records in row-major
+// order (x = kept scores, one byte per pixel of the lane's dword; y = lane | wave-cell of each of the 4 pixels << 6 | row
+// << 18), cellMax[8] is zero, seg[] describes the tile's segments (first lane, first wave-cell, x and y origin).
+template <int CAP>
+__device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t, const LevelGeom &L, int f, int level, int nSeg,
+                                           int nCellsTotal, int lane, int listCount, uint2 *list, int *cellMax, const int4 *seg) {
+    // ---- flush: per-cell maximum -> threshold, one reservation in the level's dense array, candidates grouped by cell
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (listCount > CAP) {
+        if (lane == 0) atomicOr(a.status, 4);
+        listCount = CAP;
+    }
+    // a record's lane gives its segment (sSeg), the segment gives the cell numbering and the output origin
+    auto rec_seg = [&](uint32_t recLane) {
+        int si = 0;
+        for (int k = 1; k < nSeg; k++) si += (int)recLane >= seg[k].x ? 1 : 0;   // segments are in lane order
+        return seg[si];
+    };
+    // pass A: cell maxima
+    for (int i0 = 0; i0 < listCount; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < listCount) {
+            const uint2 rec = list[i];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int sv = (rec.x >> (8 * b)) & 0xFF;
+                if (sv) atomicMax(&cellMax[(rec.y >> (6 + 3 * b)) & 7], sv);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int cntCell[kFastMaxCells];
+    uint32_t iniCells = 0;   // bit c: cell c has a survivor above iniTh, so iniTh is its threshold
+#pragma unroll
+    for (int c = 0; c < kFastMaxCells; c++) {
+        iniCells |= (c < nCellsTotal && cellMax[c] > a.iniTh) ? (1u << c) : 0u;
+        cntCell[c] = 0;
+    }
+    // A record holds at most two kept scores (one cell's, never adjacent pixels).  slots(): the candidates of a record as two slots,
+    // (wave-cell, byte) of the first and of the second byte that passes its cell's threshold; cell 15 = none.
+    auto slots = [&](const uint2 &rec, int &c0, int &b0, int &c1, int &b1) {
+        uint32_t pass = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int sv = (rec.x >> (8 * b)) & 0xFF, cw = (rec.y >> (6 + 3 * b)) & 7;
+            const int th = (iniCells >> cw) & 1 ? a.iniTh : a.minTh;
+            pass |= sv > th ? (1u << b) : 0u;
+        }
+        b0 = pass ? __builtin_ctz(pass) : 0;
+        b1 = pass ? 31 - __builtin_clz(pass) : 0;
+        c0 = pass ? (int)((rec.y >> (6 + 3 * b0)) & 7) : 15;
+        c1 = (pass && b1 != b0) ? (int)((rec.y >> (6 + 3 * b1)) & 7) : 15;
+    };
+    // pass B: candidates per cell
+    for (int i0 = 0; i0 < listCount; i0 += 64) {
+        const int i = i0 + lane;
+        const uint2 rec = i < listCount ? list[i] : make_uint2(0u, 0u);
+        int c0, b0, c1, b1;
+        slots(rec, c0, b0, c1, b1);
+#pragma unroll
+        for (int c = 0; c < kFastMaxCells; c++) cntCell[c] += __popcll(__ballot(c0 == c)) + __popcll(__ballot(c1 == c));
+    }
+    int offCell[kFastMaxCells], total = 0;
+#pragma unroll
+    for (int c = 0; c < kFastMaxCells; c++) { offCell[c] = total; total += cntCell[c]; }
+    int base = 0;
+    if (lane == 0 && total) base = atomicAdd(&a.levelCount[f * kMaxLevels + level], total);
+    base = __shfl(base, 0);
+    {
+        // lane c writes the table entry of wave-cell c: find its segment, then (cell row, cell column)
+        int tabIdx = -1;
+        int cellsBefore = 0;
+        for (int sgi = 0; sgi < nSeg; sgi++) {
+            const FastSeg sg = t.seg[sgi];
+            if (lane >= cellsBefore && lane < cellsBefore + sg.nCells) tabIdx = sg.cellRow * L.nCols + sg.c0 + (lane - cellsBefore);
+            cellsBefore += sg.nCells;
+        }
+        int2 *tab = a.cellTab + (size_t)f * a.g.totalCells + L.cellBase;
+#pragma unroll
+        for (int c = 0; c < kFastMaxCells; c++)
+            if (lane == c && tabIdx >= 0) tab[tabIdx] = make_int2(base + offCell[c], cntCell[c]);
+    }
+    Cand *out = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
+    int run[kFastMaxCells];
+#pragma unroll
+    for (int c = 0; c < kFastMaxCells; c++) run[c] = base + offCell[c];
+    // pass C: write, records ascending then bytes ascending inside each cell (= cv::FAST's row-major order)
+    for (int i0 = 0; i0 < listCount; i0 += 64) {
+        const int i = i0 + lane;
+        const uint2 rec = i < listCount ? list[i] : make_uint2(0u, 0u);
+        int c0, b0, c1, b1;
+        slots(rec, c0, b0, c1, b1);
+        int pos0 = -1, pos1 = -1;
+#pragma unroll
+        for (int c = 0; c < kFastMaxCells; c++) {
+            const unsigned long long B0 = __ballot(c0 == c), B1 = __ballot(c1 == c);
+            const int before = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
+                               __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0));
+            if (c0 == c) pos0 = before;
+            if (c1 == c) pos1 = before + (c0 == c ? 1 : 0);
+            run[c] += __popcll(B0) + __popcll(B1);
+        }
+        if (pos0 >= 0) {
+            const int4 sg = rec_seg(rec.y & 63);
+            const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;   // x - Xs of byte 0
+            const int yo = (int)(rec.y >> 18) + sg.w;
+            // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
+            if (pos0 < L.candCap) {
+                Cand cnd;
+                cnd.x = (uint16_t)(rel0 + b0 + sg.z);
+                cnd.y = (uint16_t)yo;
+                cnd.resp = (uint16_t)(((rec.x >> (8 * b0)) & 0xFF) - 1);
+                cnd.pad = 0;
+                out[pos0] = cnd;
+            }
+            if (pos1 >= 0 && pos1 < L.candCap) {
+                Cand cnd;
+                cnd.x = (uint16_t)(rel0 + b1 + sg.z);
+                cnd.y = (uint16_t)yo;
+                cnd.resp = (uint16_t)(((rec.x >> (8 * b1)) & 0xFF) - 1);
+                cnd.pad = 0;
+                out[pos1] = cnd;
+            }
+        }
+    }
+}
+
 template <int CAP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
     __shared__ uint2 sList[WAVES][CAP];
@@ -342,127 +471,7 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
         emit_row((pe | (po << 8)) & ownMask, dh - 1);
     }
 
-    // ---- flush: per-cell maximum -> threshold, one reservation in the level's dense array, candidates grouped by cell
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (listCount > CAP) {
-        if (lane == 0) atomicOr(a.status, 4);
-        listCount = CAP;
-    }
-    // a record's lane gives its segment (sSeg), the segment gives the cell numbering and the output origin
-    auto rec_seg = [&](uint32_t recLane) {
-        int si = 0;
-        for (int k = 1; k < nSeg; k++) si += (int)recLane >= sSeg[wvi][k].x ? 1 : 0;   // segments are in lane order
-        return sSeg[wvi][si];
-    };
-    // pass A: cell maxima
-    for (int i0 = 0; i0 < listCount; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < listCount) {
-            const uint2 rec = sList[wvi][i];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int sv = (rec.x >> (8 * b)) & 0xFF;
-                if (sv) atomicMax(&sCellMax[wvi][(rec.y >> (6 + 3 * b)) & 7], sv);
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int cntCell[kFastMaxCells];
-    uint32_t iniCells = 0;   // bit c: cell c has a survivor above iniTh, so iniTh is its threshold
-#pragma unroll
-    for (int c = 0; c < kFastMaxCells; c++) {
-        iniCells |= (c < nCellsTotal && sCellMax[wvi][c] > a.iniTh) ? (1u << c) : 0u;
-        cntCell[c] = 0;
-    }
-    // A record holds at most two kept scores (one cell's, never adjacent pixels).  slots(): the candidates of a record as two slots,
-    // (wave-cell, byte) of the first and of the second byte that passes its cell's threshold; cell 15 = none.
-    auto slots = [&](const uint2 &rec, int &c0, int &b0, int &c1, int &b1) {
-        uint32_t pass = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int sv = (rec.x >> (8 * b)) & 0xFF, cw = (rec.y >> (6 + 3 * b)) & 7;
-            const int th = (iniCells >> cw) & 1 ? a.iniTh : a.minTh;
-            pass |= sv > th ? (1u << b) : 0u;
-        }
-        b0 = pass ? __builtin_ctz(pass) : 0;
-        b1 = pass ? 31 - __builtin_clz(pass) : 0;
-        c0 = pass ? (int)((rec.y >> (6 + 3 * b0)) & 7) : 15;
-        c1 = (pass && b1 != b0) ? (int)((rec.y >> (6 + 3 * b1)) & 7) : 15;
-    };
-    // pass B: candidates per cell
-    for (int i0 = 0; i0 < listCount; i0 += 64) {
-        const int i = i0 + lane;
-        const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
-        int c0, b0, c1, b1;
-        slots(rec, c0, b0, c1, b1);
-#pragma unroll
-        for (int c = 0; c < kFastMaxCells; c++) cntCell[c] += __popcll(__ballot(c0 == c)) + __popcll(__ballot(c1 == c));
-    }
-    int offCell[kFastMaxCells], total = 0;
-#pragma unroll
-    for (int c = 0; c < kFastMaxCells; c++) { offCell[c] = total; total += cntCell[c]; }
-    int base = 0;
-    if (lane == 0 && total) base = atomicAdd(&a.levelCount[f * kMaxLevels + level], total);
-    base = __shfl(base, 0);
-    {
-        // lane c writes the table entry of wave-cell c: find its segment, then (cell row, cell column)
-        int tabIdx = -1;
-        int cellsBefore = 0;
-        for (int sgi = 0; sgi < nSeg; sgi++) {
-            const FastSeg sg = t.seg[sgi];
-            if (lane >= cellsBefore && lane < cellsBefore + sg.nCells) tabIdx = sg.cellRow * L.nCols + sg.c0 + (lane - cellsBefore);
-            cellsBefore += sg.nCells;
-        }
-        int2 *tab = a.cellTab + (size_t)f * a.g.totalCells + L.cellBase;
-#pragma unroll
-        for (int c = 0; c < kFastMaxCells; c++)
-            if (lane == c && tabIdx >= 0) tab[tabIdx] = make_int2(base + offCell[c], cntCell[c]);
-    }
-    Cand *out = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
-    int run[kFastMaxCells];
-#pragma unroll
-    for (int c = 0; c < kFastMaxCells; c++) run[c] = base + offCell[c];
-    // pass C: write, records ascending then bytes ascending inside each cell (= cv::FAST's row-major order)
-    for (int i0 = 0; i0 < listCount; i0 += 64) {
-        const int i = i0 + lane;
-        const uint2 rec = i < listCount ? sList[wvi][i] : make_uint2(0u, 0u);
-        int c0, b0, c1, b1;
-        slots(rec, c0, b0, c1, b1);
-        int pos0 = -1, pos1 = -1;
-#pragma unroll
-        for (int c = 0; c < kFastMaxCells; c++) {
-            const unsigned long long B0 = __ballot(c0 == c), B1 = __ballot(c1 == c);
-            const int before = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
-                               __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0));
-            if (c0 == c) pos0 = before;
-            if (c1 == c) pos1 = before + (c0 == c ? 1 : 0);
-            run[c] += __popcll(B0) + __popcll(B1);
-        }
-        if (pos0 >= 0) {
-            const int4 sg = rec_seg(rec.y & 63);
-            const int rel0 = 4 * ((int)(rec.y & 63) - sg.x) - 4;   // x - Xs of byte 0
-            const int yo = (int)(rec.y >> 18) + sg.w;
-            // cv::FAST reports window coordinates (detection pixel + 3); the reference adds (j*wCell, i*hCell) (:822-823)
-            if (pos0 < L.candCap) {
-                Cand cnd;
-                cnd.x = (uint16_t)(rel0 + b0 + sg.z);
-                cnd.y = (uint16_t)yo;
-                cnd.resp = (uint16_t)(((rec.x >> (8 * b0)) & 0xFF) - 1);
-                cnd.pad = 0;
-                out[pos0] = cnd;
-            }
-            if (pos1 >= 0 && pos1 < L.candCap) {
-                Cand cnd;
-                cnd.x = (uint16_t)(rel0 + b1 + sg.z);
-                cnd.y = (uint16_t)yo;
-                cnd.resp = (uint16_t)(((rec.x >> (8 * b1)) & 0xFF) - 1);
-                cnd.pad = 0;
-                out[pos1] = cnd;
-            }
-        }
-    }
+    fast_flush<CAP>(a, t, L, f, level, nSeg, nCellsTotal, lane, listCount, sList[wvi], sCellMax[wvi], sSeg[wvi]);
 }
 
 }  // namespace orbfe

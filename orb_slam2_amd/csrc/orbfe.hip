@@ -24,6 +24,7 @@
 #include "k_blur.h"
 #include "k_describe.h"
 #include "k_fast.h"
+#include "k_fast_sparse.h"
 #include "k_match.h"
 #include "k_pyramid.h"
 #include "k_quadtree.h"
@@ -134,7 +135,10 @@ struct orbfe_extractor {
     ImgSrc last{};
     int lastFrames = 0;
     bool overflow = false;
-    bool fastBigList = false;           // FAST runs with the large per-wave survivor list (set after an overflow report)
+    // FAST kernel variant: 0 = sparse (k_fast_sparse.h; opt-in through ORBFE_FAST_VARIANT=0, faster only where few pixels
+    // pass the compass test), 1 = dense (k_fast.h, the default), 2 = dense with the large per-wave survivor list.  A tile
+    // that overflows a list of the running variant reports it, and the handle moves to the next variant.
+    int fastVariant = 1;
     struct BatchCall { const uint8_t *imgs; int F, w, h, stride; size_t frameStride; orbfe_keypoint *kps; uint8_t *desc;
                        int32_t *counts; int cap; } lastCall{};
     int batchesInFlight = 0;            // orbfe_extract_batch calls since the last synchronisation
@@ -160,10 +164,10 @@ struct orbfe_extractor {
     long candTotal = 0, kpTotal = 0;
 };
 
-constexpr int kRerunBigList = 1;   // internal: eval_status asks for the batch to be run again (large FAST survivor list)
+constexpr int kRerunBigList = 1;   // internal: eval_status asks for the batch to be run again (next FAST kernel variant)
 static const char *const kBigListMsg =
-    "a FAST strip produced more survivor records than the normal kernel variant holds and more than one asynchronous batch "
-    "was in flight: the handle now uses the large-list variant, run those batches again";
+    "a FAST strip produced more candidates than the running kernel variant holds and more than one asynchronous batch "
+    "was in flight: the handle now uses the next variant, run those batches again";
 static int fetch_status(orbfe_extractor *e);
 
 namespace {
@@ -679,10 +683,13 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         // same rule is "S > max(t, 1)" (for t >= 1 the two readings agree, see k_fast.h).
         a.iniTh = std::max(a.iniTh, 1);
         a.minTh = std::max(a.minTh, 1);
-        if (e->fastBigList)   // a strip of an earlier batch produced more survivor records than the normal variant holds
+        if (e->fastVariant >= 2)   // a strip of an earlier batch produced more survivor records than the normal variant holds
             hipLaunchKernelGGL((fast_cells_kernel<kFastListCapMax, 1>), dim3(a.nTiles, F), dim3(64), 0, st, a);
-        else
+        else if (e->fastVariant == 1)
             hipLaunchKernelGGL((fast_cells_kernel<kFastListCap, 4>), dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((fast_cells_sparse_kernel<kFsWaves>), dim3((a.nTiles + kFsWaves - 1) / kFsWaves, F), dim3(64 * kFsWaves),
+                               0, st, a);
     }
     if (profAny) HIPCHK(hipEventRecord(e->ev[2], st));
     const bool hostTree = quadtree_on_host(e);
@@ -812,6 +819,7 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         }
     }
     if (const char *ov = getenv("ORBFE_OVERLAP")) e->overlap = atoi(ov) != 0;
+    if (const char *fv = getenv("ORBFE_FAST_VARIANT")) e->fastVariant = std::min(std::max(atoi(fv), 0), 2);
     *out = e;
     return ORBFE_OK;
 }
@@ -909,8 +917,8 @@ static int eval_status(orbfe_extractor *e) {
     if (st & 1) e->overflow = true;
     if (st & 2) return fail(ORBFE_ERR_CAPACITY, "quadtree node table overflow");
     if (st & 4) {
-        if (e->fastBigList) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list overflowed its upper bound (internal error)");
-        e->fastBigList = true;
+        if (e->fastVariant >= 2) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list overflowed its upper bound (internal error)");
+        e->fastVariant++;
         return kRerunBigList;
     }
     if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
@@ -931,7 +939,7 @@ int orbfe_synchronize(orbfe_extractor *e) {
     int rc = fetch_status(e);
     const int pending = e->batchesInFlight;
     e->batchesInFlight = 0;
-    if (rc == kRerunBigList) {
+    for (int attempt = 0; attempt < 2 && rc == kRerunBigList; attempt++) {
         // an asynchronous batch: its arguments are still the caller's to keep alive until this call, so it can be run again
         if (pending != 1) return fail(ORBFE_ERR_CAPACITY, kBigListMsg);
         const orbfe_extractor::BatchCall c = e->lastCall;
@@ -996,7 +1004,7 @@ int orbfe_extract_sequence(orbfe_extractor *e, const uint8_t *host_imgs, int n_f
         HIPCHK(e->seqCnt[b].ensure((size_t)chunk * sizeof(int32_t)));
     }
     const int nChunks = (n_frames + chunk - 1) / chunk;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         // chunk k: copy in on seqInStream, extract on the handle's stream, copy out on seqOutStream; buffers alternate, so the
         // copy-in of chunk k+1 and the copy-out of chunk k-1 run under the kernels of chunk k
         for (int k = 0; k < nChunks; k++) {
@@ -1053,7 +1061,7 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
     for (int y = 0; y < h; y++) memcpy((uint8_t *)e->hImg.p + (size_t)y * pitch, img + (size_t)y * stride, (size_t)w);
     HIPCHK(hipMemcpyAsync(e->dImg.p, e->hImg.p, fs, hipMemcpyHostToDevice, e->stream));
     int n = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         rc = run_batch(e, (const uint8_t *)e->dImg.p, 1, w, h, pitch, round_up((int)fs, 16), (orbfe_keypoint *)e->dKps.p,
                        (uint8_t *)e->dDesc.p, (int32_t *)e->dCounts.p, icap);
         if (rc) return rc;
