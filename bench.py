@@ -587,6 +587,28 @@ def main():
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = other_configs(local_rank, dev)
+        if nh == 1 and B > 2 * launch:
+            # the same step with its launches dealt round-robin to three handles (three HIP streams): the latency-bound stages of
+            # one launch run under the issue-bound stages of another.  Not the headline: the event time around FAST, and with it
+            # roofline.frac, is stretched by whatever else is resident.
+            exs3 = exs + [capi.ORBextractor(NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank) for _ in range(2)]
+
+            def step3():
+                for i, f0 in enumerate(range(0, B, launch)):
+                    n = min(launch, B - f0)
+                    exs3[i % 3].extract_batch_device(frames[f0].data_ptr(), n, W, H, stride, stride * H, kps[f0].data_ptr(),
+                                                     desc[f0].data_ptr(), cnt[f0:].data_ptr(), cap, sync=False)
+
+            step3()
+            for ex in exs3:
+                ex.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(5):
+                step3()
+            for ex in exs3:
+                ex.synchronize()
+            t3 = (time.perf_counter() - t3) / 5
+            extras["same_step_on_3_handles"] = {"frames_per_s": round(B / t3, 1), "ms_per_step": round(t3 * 1e3, 3), "handles": 3}
 
     if rank == 0:
         out = {

@@ -9,7 +9,7 @@ from orb_slam2_amd import capi, synth
 W, H = 1241, 376
 stride = (W + 63) // 64 * 64
 uniq = synth.frame_sequence(8, W, H)
-B = 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 host = np.zeros((B, H, stride), np.uint8)
 for i in range(B):
     host[i, :, :W] = uniq[i % 8]
