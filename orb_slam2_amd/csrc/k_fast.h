@@ -161,6 +161,17 @@ __device__ __forceinline__ void fast_row_pairs(uint32_t raw, uint32_t (&q)[8]) {
     q[7] = ER;
 }
 
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ---- the end of a tile, shared by the dense and the sparse kernel: `list` holds the wave's survivor records in row-major
 // order (x = kept scores, one byte per pixel of the lane's dword; y = lane | wave-cell of each of the 4 pixels << 6 | row
 // << 18), cellMax[8] is zero, seg[] describes the tile's segments (first lane, first wave-cell, x and y origin).
@@ -246,24 +257,31 @@ __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t,
             if (lane == c && tabIdx >= 0) tab[tabIdx] = make_int2(base + offCell[c], cntCell[c]);
     }
     Cand *out = a.cand + (size_t)f * a.g.candFrameCap + L.candOff;
-    int run[kFastMaxCells];
+    // lane c (c < 8) carries the next output position of wave-cell c
+    int runV = 0;
 #pragma unroll
-    for (int c = 0; c < kFastMaxCells; c++) run[c] = base + offCell[c];
-    // pass C: write, records ascending then bytes ascending inside each cell (= cv::FAST's row-major order)
+    for (int c = 0; c < kFastMaxCells; c++) runV = lane == c ? base + offCell[c] : runV;
+    // pass C: write, records ascending then bytes ascending inside each cell (= cv::FAST's row-major order).  The rank of a
+    // slot among the chunk's slots of the same cell comes from ONE prefix sum over the lanes of eight byte counters (a lane
+    // adds at most 2, a chunk at most 128 per cell), instead of two ballots per cell.
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         const uint2 rec = i < listCount ? list[i] : make_uint2(0u, 0u);
         int c0, b0, c1, b1;
         slots(rec, c0, b0, c1, b1);
-        int pos0 = -1, pos1 = -1;
-#pragma unroll
-        for (int c = 0; c < kFastMaxCells; c++) {
-            const unsigned long long B0 = __ballot(c0 == c), B1 = __ballot(c1 == c);
-            const int before = run[c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(B0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B0, 0)) +
-                               __builtin_amdgcn_mbcnt_hi((uint32_t)(B1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B1, 0));
-            if (c0 == c) pos0 = before;
-            if (c1 == c) pos1 = before + (c0 == c ? 1 : 0);
-            run[c] += __popcll(B0) + __popcll(B1);
+        const uint32_t one0 = c0 < 8 ? 1u << (8 * (c0 & 3)) : 0u, one1 = c1 < 8 ? 1u << (8 * (c1 & 3)) : 0u;
+        const uint32_t lo = (c0 < 4 ? one0 : 0u) + (c1 < 4 ? one1 : 0u), hi = (c0 >= 4 ? one0 : 0u) + (c1 >= 4 ? one1 : 0u);
+        const uint32_t inLo = (uint32_t)wave_incl_scan((int)lo), inHi = (uint32_t)wave_incl_scan((int)hi);
+        const uint32_t exLo = inLo - lo, exHi = inHi - hi;
+        const int rank0 = (int)(((c0 < 4 ? exLo : exHi) >> (8 * (c0 & 3))) & 0xFFu);
+        const int rank1 = (int)(((c1 < 4 ? exLo : exHi) >> (8 * (c1 & 3))) & 0xFFu) + (c1 == c0 ? 1 : 0);
+        // (every lane takes part in the permutes: a lane switched off could not be read by the others)
+        const int run0 = __builtin_amdgcn_ds_bpermute(4 * (c0 & 7), runV), run1 = __builtin_amdgcn_ds_bpermute(4 * (c1 & 7), runV);
+        const int pos0 = c0 < 8 ? run0 + rank0 : -1;
+        const int pos1 = c1 < 8 ? run1 + rank1 : -1;
+        {
+            const uint32_t tLo = (uint32_t)__builtin_amdgcn_readlane((int)inLo, 63), tHi = (uint32_t)__builtin_amdgcn_readlane((int)inHi, 63);
+            runV += lane < kFastMaxCells ? (int)(((lane < 4 ? tLo : tHi) >> (8 * (lane & 3))) & 0xFFu) : 0;
         }
         if (pos0 >= 0) {
             const int4 sg = rec_seg(rec.y & 63);
@@ -328,14 +346,12 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
     // lanes past the row (or left of it, for idle lanes): a legal address, value unused (needed pixels are in [16, w-16))
     const int xl = min(max(x0, 0), pitch - 4);
     const uint32_t rowOff = (uint32_t)((Y0 - 3) * pitch + xl);
-    uint32_t ownMask = 0;                        // per byte: is the pixel a detection pixel of this lane's segment
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int x = x0 + b;
-        ownMask |= (x >= Xs && x < Xe) ? (0xFFu << (8 * b)) : 0u;
-    }
-    // record tag: lane | wave-cell (0..7) of each of the lane's 4 pixels << 6, 3 bits each; the row goes to bit 18
-    uint32_t recTag = (uint32_t)lane;
+    // Per byte b of the lane's dword (pixel x = x0 + b): is it a detection pixel of the lane's segment (ownMask), which
+    // wave-cell it lies in (recTag: lane | cell (0..7) of each pixel << 6, 3 bits each; the row goes to bit 18), and whether its
+    // left / right neighbour lies in the same cell (16-bit lanes of 0xFFFF in mL*, mR*).  One division by the cell width per
+    // lane: x0 - Xs is a multiple of 4 and the cells are wider than 4 pixels, so the four pixels are in the cell of byte 0 or
+    // in the next one.  Pixels left of the segment (the halo lane, idle lanes) count as cell 0 without neighbours.
+    uint32_t ownMask = 0, recTag = (uint32_t)lane, sameCell = 0xFFu, mLe, mLo, mRe, mRo;
     {
         int segCell0 = 0, cellsBefore = 0;
         for (int sgi = 0; sgi < nSeg; sgi++) {
@@ -343,36 +359,31 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
             if (lane >= sg.lane0 && lane < sg.lane0 + sg.nLanes) segCell0 = cellsBefore;
             cellsBefore += sg.nCells;
         }
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int rel = x0 + b - Xs;
-            int cis = 0;
-#pragma unroll
-            for (int c = 1; c < kFastMaxCells; c++) cis += rel >= c * L.wCell ? 1 : 0;
-            recTag |= (uint32_t)min(segCell0 + cis, kFastMaxCells - 1) << (6 + 3 * b);
-        }
-    }
-    // bytes of the lane's dword that lie in the same cell as byte 0 (all of them unless a cell edge cuts the dword)
-    uint32_t sameCell = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-        sameCell |= (((recTag >> (6 + 3 * b)) & 7) == ((recTag >> 6) & 7)) ? (0xFFu << (8 * b)) : 0u;
-    if (lane < 8) sCellMax[wvi][lane] = 0;
-    int listCount = 0;   // wave-uniform
-    // per-lane cell-edge masks (16-bit lanes of 0xFFFF where the neighbour on that side is inside the pixel's cell)
-    uint32_t mLe, mLo, mRe, mRo;
-    {
+        const int rel0 = x0 - Xs;                                   // -4 for the left halo lane
+        const int n0 = max(rel0, 0);
+        const int q0 = (int)(((uint32_t)n0 * (uint32_t)L.wCellRcp) >> 16), r0 = n0 - q0 * L.wCell;
         uint32_t ml[4], mr[4];
+        int cellB0 = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int x = x0 + b, rel = x - kEdge;
-            const int c = rel >= 0 ? rel % L.wCell : 0;
-            ml[b] = (rel > 0 && c != 0) ? 0xFFFFu : 0u;
-            mr[b] = (rel >= 0 && c != L.wCell - 1 && x != w - kEdge - 1) ? 0xFFFFu : 0u;
+            const int x = x0 + b;
+            const bool in = rel0 >= 0;
+            const bool wrap = r0 + b >= L.wCell;
+            const int cis = in ? q0 + (wrap ? 1 : 0) : 0, cc = in ? (wrap ? r0 + b - L.wCell : r0 + b) : 0;
+            const int cell = min(segCell0 + cis, kFastMaxCells - 1);
+            if (b == 0) cellB0 = cell;
+            ownMask |= (x >= Xs && x < Xe) ? (0xFFu << (8 * b)) : 0u;
+            recTag |= (uint32_t)cell << (6 + 3 * b);
+            if (b) sameCell |= cell == cellB0 ? (0xFFu << (8 * b)) : 0u;
+            // (x - kEdge) and (x - Xs) differ by whole cells: the same position inside the cell
+            ml[b] = (in && x > kEdge && cc != 0) ? 0xFFFFu : 0u;
+            mr[b] = (in && cc != L.wCell - 1 && x != w - kEdge - 1) ? 0xFFFFu : 0u;
         }
         mLe = ml[0] | (ml[2] << 16); mLo = ml[1] | (ml[3] << 16);
         mRe = mr[0] | (mr[2] << 16); mRo = mr[1] | (mr[3] << 16);
     }
+    if (lane < 8) sCellMax[wvi][lane] = 0;
+    int listCount = 0;   // wave-uniform
     const u16x2 thPair = as_pk((uint32_t)a.minTh | ((uint32_t)a.minTh << 16));
 
     uint32_t Q[7][8];
@@ -451,16 +462,16 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
             const u16x2 ro = as_pk(__builtin_amdgcn_alignbit(seR, as_u32(se), 16) & mRo);
             cur.he = pkmax(le, re);
             cur.ho = pkmax(lo, ro);
-            cur.me = pkmax(cur.he, se);
-            cur.mo = pkmax(cur.ho, so);
+            cur.me = pkmax3(cur.he, se, thPair);   // minTh rides along: every real row's (me, mo) is >= minTh, so the 3x3
+            cur.mo = pkmax3(cur.ho, so, thPair);   // maximum below already holds max(neighbours, minTh)
             // ---- output row o = c-1 (`prev`): rows o-1 = pp, o+1 = cur.  The score rows start out as zeros, so for c = 0
             //      (no row yet: prev is all zero, nothing is kept) and c = 1 (the cell's first row: pp is still the zero row,
             //      as NMS must not look above the cell) no masking is needed.
-            u16x2 ne = pkmax(prev.he, ppMe), no = pkmax(prev.ho, ppMo);
-            ne = pkmax(ne, cur.me);
-            no = pkmax(no, cur.mo);
+            // (scores are 0..255: as half-precision bit patterns these are subnormals, which v_pk_maximum3_f16 orders like the
+            // integers as long as f16 denormals are not flushed -- the kernel's default mode; every GPU parity test checks it)
+            const u16x2 ne = pkmax3(prev.he, ppMe, cur.me), no = pkmax3(prev.ho, ppMo, cur.mo);
             // keep S iff S > max(neighbours, minTh)
-            const uint32_t pe = pk_keep_above(prev.se, pkmax(ne, thPair), one), po = pk_keep_above(prev.so, pkmax(no, thPair), one);
+            const uint32_t pe = pk_keep_above(prev.se, ne, one), po = pk_keep_above(prev.so, no, one);
             emit_row((pe | (po << 8)) & ownMask, c - 1);
         }
     }

@@ -40,17 +40,6 @@ constexpr int kFsMaxWait = 8;        // rows an entry may wait (ring: rows c-9 .
 constexpr int kFsWaves = 2;         // wavefronts per workgroup (16.5 KB of LDS each)
 constexpr int kFsMaxRows = 62;       // rows of a tile the 6-bit row field and the list bounds are good for
 
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 __device__ __forceinline__ int lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }

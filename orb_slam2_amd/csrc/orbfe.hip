@@ -277,6 +277,7 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
             return fail(ORBFE_ERR_UNSUPPORTED, "pyramid level " + std::to_string(l) + " is smaller than one 30-px FAST cell "
                                                "plus borders (the reference divides by zero there)");
         L.wCell = (int)std::ceil(width / L.nCols);
+        L.wCellRcp = (65536 + L.wCell - 1) / L.wCell;
         L.hCell = (int)std::ceil(height / L.nRows);
         if (L.wCell > 64 || L.hCell > 64)   // cannot happen for 30-px cells (wCell < 60), kept as a guard for the select kernel
             return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell wider than a wavefront");
