@@ -174,7 +174,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 
 // ---- the end of a tile, shared by the dense and the sparse kernel: `list` holds the wave's survivor records in row-major
 // order (x = kept scores, one byte per pixel of the lane's dword; y = lane | wave-cell of each of the 4 pixels << 6 | row
-// << 18), cellMax[8] is zero, seg[] describes the tile's segments (first lane, first wave-cell, x and y origin).
+// << 18), cellMax[16] is zero, seg[] describes the tile's segments (first lane, first wave-cell, x and y origin).
 template <int CAP>
 __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t, const LevelGeom &L, int f, int level, int nSeg,
                                            int nCellsTotal, int lane, int listCount, uint2 *list, int *cellMax, const int4 *seg) {
@@ -191,7 +191,8 @@ __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t,
         for (int k = 1; k < nSeg; k++) si += (int)recLane >= seg[k].x ? 1 : 0;   // segments are in lane order
         return seg[si];
     };
-    // pass A: cell maxima
+    // pass A: per cell the maximum kept score and two counters, kept scores (low half) and kept scores above iniTh (high
+    // half): the cell's threshold is iniTh iff its maximum is above iniTh, and its candidates are then the second counter
     for (int i0 = 0; i0 < listCount; i0 += 64) {
         const int i = i0 + lane;
         if (i < listCount) {
@@ -199,7 +200,11 @@ __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t,
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int sv = (rec.x >> (8 * b)) & 0xFF;
-                if (sv) atomicMax(&cellMax[(rec.y >> (6 + 3 * b)) & 7], sv);
+                if (sv) {
+                    const int cw = (rec.y >> (6 + 3 * b)) & 7;
+                    atomicMax(&cellMax[cw], sv);
+                    atomicAdd(&cellMax[kFastMaxCells + cw], sv > a.iniTh ? 0x10001 : 1);
+                }
             }
         }
     }
@@ -209,8 +214,10 @@ __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t,
     uint32_t iniCells = 0;   // bit c: cell c has a survivor above iniTh, so iniTh is its threshold
 #pragma unroll
     for (int c = 0; c < kFastMaxCells; c++) {
-        iniCells |= (c < nCellsTotal && cellMax[c] > a.iniTh) ? (1u << c) : 0u;
-        cntCell[c] = 0;
+        const bool ini = c < nCellsTotal && cellMax[c] > a.iniTh;
+        const int both = cellMax[kFastMaxCells + c];
+        iniCells |= ini ? (1u << c) : 0u;
+        cntCell[c] = c < nCellsTotal ? (ini ? both >> 16 : both & 0xFFFF) : 0;
     }
     // A record holds at most two kept scores (one cell's, never adjacent pixels).  slots(): the candidates of a record as two slots,
     // (wave-cell, byte) of the first and of the second byte that passes its cell's threshold; cell 15 = none.
@@ -227,15 +234,6 @@ __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t,
         c0 = pass ? (int)((rec.y >> (6 + 3 * b0)) & 7) : 15;
         c1 = (pass && b1 != b0) ? (int)((rec.y >> (6 + 3 * b1)) & 7) : 15;
     };
-    // pass B: candidates per cell
-    for (int i0 = 0; i0 < listCount; i0 += 64) {
-        const int i = i0 + lane;
-        const uint2 rec = i < listCount ? list[i] : make_uint2(0u, 0u);
-        int c0, b0, c1, b1;
-        slots(rec, c0, b0, c1, b1);
-#pragma unroll
-        for (int c = 0; c < kFastMaxCells; c++) cntCell[c] += __popcll(__ballot(c0 == c)) + __popcll(__ballot(c1 == c));
-    }
     int offCell[kFastMaxCells], total = 0;
 #pragma unroll
     for (int c = 0; c < kFastMaxCells; c++) { offCell[c] = total; total += cntCell[c]; }
@@ -311,7 +309,7 @@ __device__ __forceinline__ void fast_flush(const FastArgs &a, const FastTile &t,
 template <int CAP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
     __shared__ uint2 sList[WAVES][CAP];
-    __shared__ int sCellMax[WAVES][kFastMaxCells];
+    __shared__ int sCellMax[WAVES][2 * kFastMaxCells];   // per wave-cell: maximum kept score; (kept, kept above iniTh) counters
     __shared__ int4 sSeg[WAVES][kFastMaxSeg];   // per segment: first lane, first cell (in wave), x and y of its origin in the output
     const int lane = threadIdx.x & 63;
     const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile record and row tests on the scalar unit
@@ -382,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_kernel(FastArgs a) {
         mLe = ml[0] | (ml[2] << 16); mLo = ml[1] | (ml[3] << 16);
         mRe = mr[0] | (mr[2] << 16); mRo = mr[1] | (mr[3] << 16);
     }
-    if (lane < 8) sCellMax[wvi][lane] = 0;
+    if (lane < 2 * kFastMaxCells) sCellMax[wvi][lane] = 0;
     int listCount = 0;   // wave-uniform
     const u16x2 thPair = as_pk((uint32_t)a.minTh | ((uint32_t)a.minTh << 16));
 

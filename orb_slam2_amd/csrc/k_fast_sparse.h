@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_sparse_kernel(FastArgs 
     __shared__ uint2 sList[WAVES][kFsListCap];
     __shared__ uint32_t sTag[WAVES][64];
     __shared__ uint32_t sEdge[WAVES][64];
-    __shared__ int sCellMax[WAVES][kFastMaxCells];
+    __shared__ int sCellMax[WAVES][2 * kFastMaxCells];
     __shared__ int4 sSeg[WAVES][kFastMaxSeg];
     const int lane = threadIdx.x & 63;
     const int wvi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES) void fast_cells_sparse_kernel(FastArgs 
     u16_alias *queue16 = reinterpret_cast<u16_alias *>(sQueue[wvi]);
     sTag[wvi][lane] = recTag;
     sEdge[wvi][lane] = edge;
-    if (lane < 8) sCellMax[wvi][lane] = 0;
+    if (lane < 2 * kFastMaxCells) sCellMax[wvi][lane] = 0;
     plane32[lane] = 0;          // row -1 (slot 0): above the cell row
     plane32[64 + lane] = 0;     // row 0
     // rows Y0-3 .. Y0+2 of the image = tile rows j = 0..5 (always inside the image), ring slot j and its mirror 16 + j
