@@ -517,8 +517,19 @@ def main():
                 idt.copy_(torch.frombuffer(bytearray(capi.sharded_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
             torch.cuda.synchronize()
-            sharded = capi.ShardedKnn2(m, bytes(idt.cpu().numpy().tobytes()), rank, world, NQ)
-        elif world > 1:
+            err = ""
+            try:
+                sharded = capi.ShardedKnn2(m, bytes(idt.cpu().numpy().tobytes()), rank, world, NQ)
+            except Exception as e:   # e.g. librccl not loadable: every rank must take the same path, or the job hangs
+                err = str(e)
+            ok = torch.tensor([1 if sharded is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if rank == 0:
+                    print(f"[bench] orbfe_knn2_sharded_create failed on a rank ({err}); falling back to torch.distributed + "
+                          "orbfe_merge_knn2", file=sys.stderr, flush=True)
+                sharded = None
+        if world > 1 and sharded is None:
             gathered = torch.zeros((world * 3, NQ), dtype=torch.int32, device=cdev)
 
         def hstep():
@@ -527,14 +538,16 @@ def main():
                             res[2].data_ptr(), sync=True)
                 return None
             if world > 1:
-                qc = q.cpu()
+                qc = q if cdev.type == "cuda" else q.cpu()
                 dist.broadcast(qc, src=0)
-                q.copy_(qc)
+                if qc is not q:
+                    q.copy_(qc)
                 torch.cuda.synchronize()      # the matcher runs on its own non-blocking stream: order it after the broadcast
             m.knn2_device(q.data_ptr(), NQ, db.data_ptr(), shard, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
                           idx_base=rank * shard, sync=True)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, res.cpu())
+                torch.cuda.synchronize()
+                dist.all_gather_into_tensor(gathered, res if cdev.type == "cuda" else res.cpu())
                 g = gathered.view(world, 3, NQ).cpu().numpy()
                 return capi.merge_knn2(g[:, 0], g[:, 1], g[:, 2])
             return None
