@@ -21,6 +21,7 @@
 #include "ORBmatcher.h"
 
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,7 @@ struct PooledGrid {
     unsigned long print = 0;   // fingerprint of the keypoints it was built from: frame ids restart after Tracking::Reset
     int n = 0;
     int users = 0;             // leases outstanding: a grid in use is never recycled
+    bool building = false;     // reserved, its upload still running outside the pool's lock
 };
 
 // a few keypoints and descriptor rows, enough to tell two frames that were given the same id apart
@@ -85,29 +87,42 @@ public:
         static GridPool *pool = new GridPool;   // never destroyed: worker threads may still search at process exit
         return *pool;
     }
-    // the grid of frame `key`, built from the given members on first use (Frame::AssignFeaturesToGrid, src/Frame.cc:230-246)
+    // the grid of frame `key`, built from the given members on first use (Frame::AssignFeaturesToGrid, src/Frame.cc:230-246).
+    // The pool's mutex covers the bookkeeping only: the entry is reserved (users = 1, building) under the lock, the host
+    // repack, the copy to the device and its synchronisation run outside it, and the entry is published through the
+    // condition variable -- so Tracking, LocalMapping and LoopClosing do not queue behind one another's uploads; a thread
+    // that wants a grid another thread is still building waits for that one entry.
     PooledGrid *acquire(orbfe_matcher *m, unsigned long key, const std::vector<cv::KeyPoint> &keysUn, const cv::Mat &desc,
                         const std::vector<float> &uRight, float minX, float minY, float wInv, float hInv) {
-        std::lock_guard<std::mutex> lock(mutex_);
         const int n = (int)keysUn.size();
         const unsigned long print = fingerprint(keysUn, desc);
-        for (std::list<PooledGrid *>::iterator it = lru_.begin(); it != lru_.end(); ++it)
-            if ((*it)->key == key && (*it)->n == n && (*it)->print == print) {
-                PooledGrid *e = *it;
-                lru_.erase(it);
-                lru_.push_front(e);
-                e->users++;
-                return e;
-            }
         PooledGrid *e = nullptr;
-        if (lru_.size() >= capacity_)
-            for (std::list<PooledGrid *>::reverse_iterator it = lru_.rbegin(); it != lru_.rend(); ++it)
-                if ((*it)->users == 0) {
-                    e = *it;
-                    lru_.erase(std::next(it).base());
-                    break;
+        {
+            std::unique_lock<std::mutex> lock(mutex_);
+            for (std::list<PooledGrid *>::iterator it = lru_.begin(); it != lru_.end(); ++it)
+                if ((*it)->key == key && (*it)->n == n && (*it)->print == print) {
+                    PooledGrid *hit = *it;
+                    lru_.erase(it);
+                    lru_.push_front(hit);
+                    hit->users++;           // leased before waiting: a grid in use is never recycled
+                    built_.wait(lock, [hit] { return !hit->building; });
+                    return hit;
                 }
-        if (!e) e = new PooledGrid;   // room left, or every grid is in use right now
+            if (lru_.size() >= capacity_)
+                for (std::list<PooledGrid *>::reverse_iterator it = lru_.rbegin(); it != lru_.rend(); ++it)
+                    if ((*it)->users == 0) {
+                        e = *it;
+                        lru_.erase(std::next(it).base());
+                        break;
+                    }
+            if (!e) e = new PooledGrid;   // room left, or every grid is in use right now (release() trims the excess)
+            e->key = key;
+            e->print = print;
+            e->n = n;
+            e->users = 1;
+            e->building = true;
+            lru_.push_front(e);
+        }
         std::vector<float> kx(n), ky(n);
         std::vector<int32_t> oct(n);
         std::vector<unsigned char> d((size_t)n * 32 + 1);
@@ -123,16 +138,32 @@ public:
         else
             check(orbfe_frame_grid_create(orbfe::default_device(), kx.data(), ky.data(), oct.data(), d.data(), ur, n, minX, minY, wInv,
                                           hInv, &e->g), "grid create");
-        e->key = key;
-        e->print = print;
-        e->n = n;
-        e->users = 1;
-        lru_.push_front(e);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            e->building = false;
+        }
+        built_.notify_all();
         return e;
     }
     void release(PooledGrid *e) {
+        PooledGrid *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            e->users--;
+            // the pool grows past its capacity only while every grid is leased; give the excess back as leases end
+            if (e->users == 0 && lru_.size() > capacity_) {
+                lru_.remove(e);
+                drop = e;
+            }
+        }
+        if (drop) {
+            if (drop->g) (void)orbfe_frame_grid_destroy(drop->g);
+            delete drop;
+        }
+    }
+    size_t size() {
         std::lock_guard<std::mutex> lock(mutex_);
-        e->users--;
+        return lru_.size();
     }
 
 private:
@@ -141,6 +172,7 @@ private:
         capacity_ = c ? (size_t)std::max(2, std::atoi(c)) : 256;
     }
     std::mutex mutex_;
+    std::condition_variable built_;
     std::list<PooledGrid *> lru_;
     size_t capacity_;
 };

@@ -512,22 +512,42 @@ def main():
         sharded = None
         gathered = None
         if world > 1 and backend == "nccl":
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(capi.sharded_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, src=0)
-            torch.cuda.synchronize()
+            # Agree on the path BEFORE anything that can block on another rank: a rank that cannot bind librccl (or rank 0
+            # failing to make the id) must not leave the others waiting in a broadcast or inside ncclCommInitRank.
+            # orbfe_knn2_sharded_available only binds the library; the flag goes through torch.distributed (MIN).
             err = ""
+            idb = b""
+            ok_local = 1
             try:
-                sharded = capi.ShardedKnn2(m, bytes(idt.cpu().numpy().tobytes()), rank, world, NQ)
-            except Exception as e:   # e.g. librccl not loadable: every rank must take the same path, or the job hangs
-                err = str(e)
-            ok = torch.tensor([1 if sharded is not None else 0], dtype=torch.int32, device=dev)
+                if not capi.sharded_available():
+                    ok_local, err = 0, capi.lib().orbfe_last_error().decode()
+                elif rank == 0:
+                    idb = capi.sharded_unique_id()
+            except Exception as e:
+                ok_local, err = 0, str(e)
+            ok = torch.tensor([ok_local], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
+            if int(ok.item()) == 1:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
                 if rank == 0:
-                    print(f"[bench] orbfe_knn2_sharded_create failed on a rank ({err}); falling back to torch.distributed + "
-                          "orbfe_merge_knn2", file=sys.stderr, flush=True)
+                    idt.copy_(torch.frombuffer(bytearray(idb), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                torch.cuda.synchronize()
+                try:
+                    # collective (ncclCommInitRank): every rank is known to have a working librccl at this point; a failure
+                    # from here on is RCCL's own (symmetric: the communicator does not form on any rank)
+                    sharded = capi.ShardedKnn2(m, bytes(idt.cpu().numpy().tobytes()), rank, world, NQ)
+                except Exception as e:
+                    err = str(e)
+                ok = torch.tensor([1 if sharded is not None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                if rank == 0:
+                    why = "; ".join(f"rank {r}: {e}" for r, e in enumerate(errs) if e) or "unknown"
+                    print(f"[bench] RCCL inside liborbfe is not available on every rank ({why}); falling back to "
+                          "torch.distributed + orbfe_merge_knn2", file=sys.stderr, flush=True)
                 sharded = None
         if world > 1 and sharded is None:
             gathered = torch.zeros((world * 3, NQ), dtype=torch.int32, device=cdev)

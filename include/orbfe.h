@@ -87,7 +87,12 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
  * apart; dev_imgs, stride and frame_stride must be multiples of 16.
  * Outputs (device): dev_kps[n_frames][cap], dev_desc[n_frames][cap][32], dev_counts[n_frames].
  * The call is asynchronous on the handle's stream unless `sync` is non-zero.  If a frame yields more than `cap`
- * keypoints its count is still reported in full and only the first `cap` entries are written. */
+ * keypoints its count is still reported in full and only the first `cap` entries are written.
+ * Asynchronous calls: the arguments (input frames and output buffers) must stay valid and unchanged until orbfe_synchronize
+ * returns.  Any number of batches may be queued; if a frame of one of them overflows the running FAST kernel's per-strip
+ * survivor list (dense noise -- the reference's std::vector just grows, src/ORBextractor.cc:779), orbfe_synchronize runs ALL
+ * batches queued since the last synchronisation again, in order, with the large-list kernel, so the outputs are the
+ * reference's whatever the content.  The handle returns to the normal kernel by itself after a number of batches. */
 int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frames, int w, int h, int stride,
                         size_t frame_stride, orbfe_keypoint *dev_kps, uint8_t *dev_desc, int32_t *dev_counts, int cap,
                         int sync);
@@ -128,6 +133,10 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
  * cos_sin[2*i+1] = b for angles_deg[i].  Host pointers; synchronous.  For the known-answer test over the angles where a
  * faster device routine used to differ from libm (tests/golden/sincos_census.json). */
 int orbfe_debug_rotation(orbfe_extractor *e, const float *angles_deg, int n, float *cos_sin);
+/* The FAST kernel variant the handle's next batch will run: 0 = sparse, 1 = dense (default), 2 = dense with the large per-strip
+ * survivor list (entered after an overflow, left again after 16, 32, ... batches).  For the tests of that recovery; no counterpart
+ * in the reference. */
+int orbfe_debug_fast_variant(const orbfe_extractor *e);
 
 /* Per-stage device timing of the extractor, taken with HIP events recorded on the handle's stream around each
  * stage's kernel launches inside orbfe_extract / orbfe_extract_batch (no counterpart in the reference, whose only
@@ -371,6 +380,10 @@ int orbfe_merge_knn2(const int32_t *best_dist, const int32_t *best_idx, const in
  * development box has -- see DESIGN.md section 6. */
 #define ORBFE_SHARDED_ID_BYTES 128
 typedef struct orbfe_knn2_sharded orbfe_knn2_sharded;
+/*   available  binds librccl (ORBFE_RCCL_LIB names another library) and does nothing else: ORBFE_OK, or ORBFE_ERR_DEVICE with the
+ *              loader's message.  Not collective, touches no GPU: every rank calls it BEFORE any call that can block on the
+ *              others, so that a job agrees on a fallback instead of hanging in ncclCommInitRank (bench.py). */
+int orbfe_knn2_sharded_available(void);
 int orbfe_knn2_sharded_unique_id(uint8_t id[ORBFE_SHARDED_ID_BYTES]);
 int orbfe_knn2_sharded_create(orbfe_matcher *m, const uint8_t id[ORBFE_SHARDED_ID_BYTES], int rank, int world, int max_queries,
                               orbfe_knn2_sharded **out);

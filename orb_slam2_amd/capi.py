@@ -33,7 +33,7 @@ EXPORTS = [
     "orbfe_search_area_ex", "orbfe_search_for_triangulation", "orbfe_extract_sequence", "orbfe_match_knn2_noalloc",
     "orbfe_knn2_sharded_unique_id", "orbfe_knn2_sharded_create", "orbfe_knn2_sharded_run", "orbfe_knn2_sharded_destroy",
     "orbfe_frame_grid_update", "orbfe_pyramid_mirror", "orbfe_bow_transform_host", "orbfe_stereo_rowband_host", "orbfe_stereo_match_host",
-    "orbfe_debug_rotation",
+    "orbfe_debug_rotation", "orbfe_knn2_sharded_available", "orbfe_debug_fast_variant",
 ]
 
 STAGES = ("pyramid", "fast", "blur", "describe", "quadtree")
@@ -92,11 +92,13 @@ def lib():
     L.orbfe_pyramid_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, i32p, i32p]
     L.orbfe_debug_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbfe_debug_rotation.argtypes = [vp, vp, C.c_int, vp]
+    L.orbfe_debug_fast_variant.argtypes = [vp]
     L.orbfe_hamming.argtypes = [vp, vp]
     L.orbfe_matcher_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.orbfe_matcher_destroy.argtypes = [vp]
     L.orbfe_match_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
     L.orbfe_match_knn2_noalloc.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
+    L.orbfe_knn2_sharded_available.argtypes = []
     L.orbfe_knn2_sharded_unique_id.argtypes = [vp]
     L.orbfe_knn2_sharded_create.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.orbfe_knn2_sharded_run.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int]
@@ -251,6 +253,10 @@ class ORBextractor:
     def stream(self) -> int:
         return int(self._L.orbfe_extractor_stream(self._h) or 0)
 
+    def fast_variant(self) -> int:
+        """orbfe_debug_fast_variant: 0 sparse, 1 dense, 2 dense with the large survivor list (after an overflow)."""
+        return int(self._L.orbfe_debug_fast_variant(self._h))
+
     # ---- mvImagePyramid (include/ORBextractor.h:85)
     def pyramid_level(self, level, frame=0, with_border=False):
         w, h = C.c_int32(), C.c_int32()
@@ -389,6 +395,12 @@ class ORBmatcher:
 
     def stream(self) -> int:
         return int(self._L.orbfe_matcher_stream(self._h) or 0)
+
+
+def sharded_available() -> bool:
+    """orbfe_knn2_sharded_available: True iff librccl could be bound.  Touches no GPU and is not collective; the loader's
+    message is in orbfe_last_error() when it returns False."""
+    return lib().orbfe_knn2_sharded_available() == 0
 
 
 def sharded_unique_id() -> bytes:

@@ -19,7 +19,8 @@ struct LevelGeom {
     int blurOff;            // byte offset inside one frame's blurred block
     int nCols, nRows;       // FAST cell grid (reference src/ORBextractor.cc:784-787)
     int wCell, hCell;
-    int wCellRcp;           // ceil(65536 / wCell): n / wCell = (n * wCellRcp) >> 16 for 0 <= n < 2000
+    int wCellRcp;           // ceil(65536 / wCell): n / wCell == (n * wCellRcp) >> 16 for STRIP-RELATIVE n only (0 <= n < 264, the
+                            // lanes of one wavefront; build_geometry checks every such n) -- not for absolute x (first miss: 62 @ 1115)
     int cellBase;           // first cell id of this level in the frame-wide cell numbering
     int candOff, candCap;   // candidate slots of this level inside one frame's candidate block
     int selOff, selCap;     // kept-keypoint slots of this level inside one frame's block

@@ -146,9 +146,18 @@ struct orbfe_extractor {
     // pass the compass test), 1 = dense (k_fast.h, the default), 2 = dense with the large per-wave survivor list.  A tile
     // that overflows a list of the running variant reports it, and the handle moves to the next variant.
     int fastVariant = 1;
+    int fastVariantBase = 1;            // the variant the handle was created with (ORBFE_FAST_VARIANT)
+    // The large-list variant is a detour, not a state: after `demoteAfter` batches on it the handle tries its own variant
+    // again (a frame of noise is an event, not a property of the sequence); if that overflows once more the batch is rerun
+    // as before and the next detour lasts twice as long (16, 32, ... 4096 batches), so a sequence that does consist of noise
+    // pays one rerun per detour, not one per batch.
+    int bigListBatches = 0, demoteAfter = 16, promotions = 0;
     struct BatchCall { const uint8_t *imgs; int F, w, h, stride; size_t frameStride; orbfe_keypoint *kps; uint8_t *desc;
-                       int32_t *counts; int cap; } lastCall{};
-    int batchesInFlight = 0;            // orbfe_extract_batch calls since the last synchronisation
+                       int32_t *counts; int cap; };
+    std::vector<BatchCall> inFlight;    // every orbfe_extract_batch call since the last synchronisation, in order: the status
+                                        // word cannot say which of them overflowed, so all of them are run again
+    bool rerunPending = false;          // an overflow of queued batches was seen outside orbfe_synchronize (workspace growth)
+    int batchesInFlight = 0;            // = inFlight.size() (kept for the paths that enqueue through run_batch directly)
     int quadtreeMode = ORBFE_QUADTREE_DEVICE;   // orbfe_set_quadtree_mode
     bool lastOnHost = false;                    // did the last call bring candidates / kept keypoints to the host
     PinBuf hStatus;
@@ -172,9 +181,6 @@ struct orbfe_extractor {
 };
 
 constexpr int kRerunBigList = 1;   // internal: eval_status asks for the batch to be run again (next FAST kernel variant)
-static const char *const kBigListMsg =
-    "a FAST strip produced more candidates than the running kernel variant holds and more than one asynchronous batch "
-    "was in flight: the handle now uses the next variant, run those batches again";
 static int fetch_status(orbfe_extractor *e);
 
 namespace {
@@ -278,6 +284,10 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
                                                "plus borders (the reference divides by zero there)");
         L.wCell = (int)std::ceil(width / L.nCols);
         L.wCellRcp = (65536 + L.wCell - 1) / L.wCell;
+        // the FAST kernels divide strip-relative pixel positions (one wavefront: < 4 * 64 + 8) by wCell with this reciprocal
+        for (int n = 0; n < 4 * 64 + 8; n++)
+            if ((int)(((uint32_t)n * (uint32_t)L.wCellRcp) >> 16) != n / L.wCell)
+                return fail(ORBFE_ERR_UNSUPPORTED, "internal: reciprocal of the FAST cell width is inexact inside a strip");
         L.hCell = (int)std::ceil(height / L.nRows);
         if (L.wCell > 64 || L.hCell > 64)   // cannot happen for 30-px cells (wCell < 60), kept as a guard for the select kernel
             return fail(ORBFE_ERR_UNSUPPORTED, "FAST cell wider than a wavefront");
@@ -453,7 +463,10 @@ int ensure_workspace(orbfe_extractor *e, int F) {
         const size_t lcBytes = (size_t)F * kMaxLevels * sizeof(int), ctBytes = (size_t)F * g.totalCells * sizeof(int2);
         e->countersBytes = 64 + lcBytes + ctBytes;
         if (e->countersBytes > e->dCounters.bytes) {   // about to move: whatever an unfinished batch reported goes first
-            if (int rc = fetch_status(e)) return rc == kRerunBigList ? fail(ORBFE_ERR_CAPACITY, kBigListMsg) : rc;
+            // (an overflow of the batches already queued is remembered for orbfe_synchronize, which runs them again)
+            const int rc = fetch_status(e);
+            if (rc == kRerunBigList) e->rerunPending = true;
+            else if (rc) return rc;
         }
         HIPCHK(e->dCounters.ensure(e->countersBytes));
         if (e->pStatus != (int *)e->dCounters.p) HIPCHK(hipMemsetAsync(e->dCounters.p, 0, 64, e->stream));
@@ -712,6 +725,10 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         // same rule is "S > max(t, 1)" (for t >= 1 the two readings agree, see k_fast.h).
         a.iniTh = std::max(a.iniTh, 1);
         a.minTh = std::max(a.minTh, 1);
+        if (e->fastVariant >= 2 && e->fastVariantBase < 2 && ++e->bigListBatches > e->demoteAfter) {
+            e->fastVariant = e->fastVariantBase;   // the detour is over: back to the handle's own variant
+            e->bigListBatches = 0;
+        }
         if (e->fastVariant >= 2)   // a strip of an earlier batch produced more survivor records than the normal variant holds
             hipLaunchKernelGGL((fast_cells_kernel<kFastListCapMax, 1>), dim3(a.nTiles, F), dim3(64), 0, st, a);
         else if (e->fastVariant == 1)
@@ -880,6 +897,7 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
     }
     if (const char *dt = getenv("ORBFE_DESCRIBE_TILED")) e->describeTiled = atoi(dt) != 0;
     if (const char *fv = getenv("ORBFE_FAST_VARIANT")) e->fastVariant = std::min(std::max(atoi(fv), 0), 2);
+    e->fastVariantBase = e->fastVariant;
     *out = e;
     return ORBFE_OK;
 }
@@ -967,6 +985,8 @@ int orbfe_debug_qt_times(unsigned long long *out, int n) {
 
 void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream : nullptr; }
 
+int orbfe_debug_fast_variant(const orbfe_extractor *e) { return e ? e->fastVariant : -1; }
+
 // after the stream has drained: fold the device status word into the handle.  The word is sticky on the device (batches
 // enqueued back to back all report into it) and cleared here.  kRerunBigList: a FAST strip overflowed the normal survivor
 // list; the handle has been switched to the large-list kernel and the caller runs the batch again.
@@ -979,6 +999,10 @@ static int eval_status(orbfe_extractor *e) {
     if (st & 4) {
         if (e->fastVariant >= 2) return fail(ORBFE_ERR_CAPACITY, "FAST survivor list overflowed its upper bound (internal error)");
         e->fastVariant++;
+        if (e->fastVariant >= 2) {
+            e->bigListBatches = 0;
+            e->demoteAfter = e->promotions++ ? std::min(e->demoteAfter * 2, 4096) : 16;
+        }
         return kRerunBigList;
     }
     if (e->overflow) return fail(ORBFE_ERR_CAPACITY, "FAST candidate buffer overflow on at least one level");
@@ -997,17 +1021,22 @@ int orbfe_synchronize(orbfe_extractor *e) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     int rc = fetch_status(e);
-    const int pending = e->batchesInFlight;
+    if (rc == ORBFE_OK && e->rerunPending) rc = kRerunBigList;
+    e->rerunPending = false;
+    const std::vector<orbfe_extractor::BatchCall> pending = std::move(e->inFlight);
+    e->inFlight.clear();
     e->batchesInFlight = 0;
     for (int attempt = 0; attempt < 2 && rc == kRerunBigList; attempt++) {
-        // an asynchronous batch: its arguments are still the caller's to keep alive until this call, so it can be run again
-        if (pending != 1) return fail(ORBFE_ERR_CAPACITY, kBigListMsg);
-        const orbfe_extractor::BatchCall c = e->lastCall;
-        rc = run_batch(e, c.imgs, c.F, c.w, c.h, c.stride, c.frameStride, c.kps, c.desc, c.counts, c.cap);
-        if (rc) return rc;
+        // Asynchronous batches: their arguments are the caller's to keep alive until this call, so they can be run again.  The
+        // status word is one per handle: every batch queued since the last synchronisation is run again, in order, on the next
+        // kernel variant (for a sparse handle, ORBFE_FAST_VARIANT=0, a second round reaches the large list).
+        if (pending.empty()) return fail(ORBFE_ERR_CAPACITY, "a FAST strip overflowed its survivor list and no batch is recorded to run again");
+        for (const orbfe_extractor::BatchCall &c : pending) {
+            rc = run_batch(e, c.imgs, c.F, c.w, c.h, c.stride, c.frameStride, c.kps, c.desc, c.counts, c.cap);
+            if (rc) return rc;
+        }
         HIPCHK(hipStreamSynchronize(e->stream));
         rc = fetch_status(e);
-        e->batchesInFlight = 0;
     }
     return rc;
 }
@@ -1030,7 +1059,7 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
     HIPCHK(hipSetDevice(e->device));
     int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap);
     if (rc) return rc;
-    e->lastCall = {dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap};
+    e->inFlight.push_back({dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap});
     e->batchesInFlight++;
     return sync ? orbfe_synchronize(e) : ORBFE_OK;
 }
@@ -1103,6 +1132,10 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
     if (!img || w <= 0 || h <= 0) return ORBFE_OK;   // _image.empty(): return with outputs untouched (:1046-1047)
     if (stride < w) return fail(ORBFE_ERR_ARG, "stride < w");
     HIPCHK(hipSetDevice(e->device));
+    if (e->batchesInFlight) {   // asynchronous batches of the caller come first, with their own status handling
+        const int rc0 = orbfe_synchronize(e);
+        if (rc0) return rc0;
+    }
     int rc = build_geometry(e, w, h);
     if (rc) return rc;
     const int pitch = round_up(w, kPitchAlign);

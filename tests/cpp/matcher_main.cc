@@ -5,10 +5,17 @@
 // method leaves behind so that the pytest driver can compare it with the oracle's sequential replay.
 // Frame / KeyFrame / MapPoint are the stand-ins of tests/cpp/stubs (the members src/ORBmatcher.cc touches).
 //   usage: matcher_main world.bin out.bin
+//          matcher_main --concurrent REPS world1.bin out1.bin world2.bin out2.bin ...
+// The second form runs every case on a host thread of its own, REPS times each, all threads released together -- the way
+// Tracking, LocalMapping and LoopClosing use ORBmatcher temporaries at once (reference src/System.cc:92-102): one liborbfe
+// matcher context per thread (include/orbfe_context.h) and ONE shared pool of device grids (adapters/ORBmatcher_orbfe.cc,
+// ORBFE_GRID_POOL sets its size).  The worlds must share the camera (the Frame statics are process-wide, as in the reference).
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <set>
+#include <thread>
 #include <vector>
 
 #include "ORBmatcher.h"
@@ -80,16 +87,30 @@ struct World {
 
 }  // namespace
 
-int main(int argc, char **argv) {
-    if (argc < 3) return 2;
-    Reader r{std::fopen(argv[1], "rb")};
+namespace {
+
+void set_camera_statics(const float *cam) {
+    Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
+    Frame::mnMinX = cam[6]; Frame::mnMaxX = cam[7]; Frame::mnMinY = cam[8]; Frame::mnMaxY = cam[9];
+    Frame::mfGridElementWidthInv = cam[10]; Frame::mfGridElementHeightInv = cam[11];
+}
+
+bool camera_statics_are(const float *cam) {
+    return Frame::fx == cam[0] && Frame::fy == cam[1] && Frame::cx == cam[2] && Frame::cy == cam[3] && Frame::mnMinX == cam[6] &&
+           Frame::mnMaxX == cam[7] && Frame::mnMinY == cam[8] && Frame::mnMaxY == cam[9] &&
+           Frame::mfGridElementWidthInv == cam[10] && Frame::mfGridElementHeightInv == cam[11];
+}
+
+// one case: load the world, run its operation through the class, dump what it left behind.  setStatics: single-case mode
+// writes the camera into the Frame statics; the concurrent mode set them before the threads started and only checks.
+int run_case(const char *inPath, const char *outPath, bool setStatics, bool quiet) {
+    Reader r{std::fopen(inPath, "rb")};
     if (!r.f) return 3;
     const int op = r.i32(), nViews = r.i32(), nPoints = r.i32();
     float cam[12];
     r.raw(cam, sizeof(cam));   // fx fy cx cy bf b minX maxX minY maxY wInv hInv
-    Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
-    Frame::mnMinX = cam[6]; Frame::mnMaxX = cam[7]; Frame::mnMinY = cam[8]; Frame::mnMaxY = cam[9];
-    Frame::mfGridElementWidthInv = cam[10]; Frame::mfGridElementHeightInv = cam[11];
+    if (setStatics) set_camera_statics(cam);
+    else if (!camera_statics_are(cam)) return 5;
     Scales S;
     S.nlevels = r.i32();
     S.scaleFactor = r.f32();
@@ -192,7 +213,7 @@ int main(int argc, char **argv) {
     r.raw(fp, sizeof(fp));   // fp[0] = nnratio, fp[1] = th
     if (!r.ok) return 3;
     ORBmatcher matcher(fp[0], ip[0] != 0);
-    Writer w{std::fopen(argv[2], "wb")};
+    Writer w{std::fopen(outPath, "wb")};
     if (!w.f) return 4;
     View &A = *W.views[0];
     View &B = *W.views[nViews > 1 ? 1 : 0];
@@ -314,6 +335,49 @@ int main(int argc, char **argv) {
     }
     if (!r.ok) return 3;
     std::fclose(w.f);
-    std::printf("matcher_main ok: op %d, result %d\n", op, result);
+    std::fclose(r.f);
+    for (View *V : W.views) delete V;
+    for (MapPoint *p : W.points) delete p;
+    if (!quiet) std::printf("matcher_main ok: op %d, result %d\n", op, result);
     return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc >= 5 && std::strcmp(argv[1], "--concurrent") == 0) {
+        const int reps = std::atoi(argv[2]);
+        const int nCases = (argc - 3) / 2;
+        if (reps < 1 || nCases < 1 || (argc - 3) % 2) return 2;
+        {
+            Reader r{std::fopen(argv[3], "rb")};
+            if (!r.f) return 3;
+            r.i32(); r.i32(); r.i32();
+            float cam[12];
+            r.raw(cam, sizeof(cam));
+            if (!r.ok) return 3;
+            set_camera_statics(cam);
+            std::fclose(r.f);
+        }
+        std::atomic<int> ready(0), failed(0);
+        std::vector<std::thread> threads;
+        for (int c = 0; c < nCases; c++)
+            threads.emplace_back([&, c] {
+                ready++;
+                while (ready.load() < nCases) std::this_thread::yield();   // all threads enter their first search together
+                for (int k = 0; k < reps; k++) {
+                    const int rc = run_case(argv[3 + 2 * c], argv[4 + 2 * c], false, true);
+                    if (rc) {
+                        failed = rc;
+                        return;
+                    }
+                }
+            });
+        for (std::thread &t : threads) t.join();
+        if (failed.load()) return failed.load();
+        std::printf("matcher_main ok: %d cases x %d repetitions on %d threads\n", nCases, reps, nCases);
+        return 0;
+    }
+    if (argc < 3) return 2;
+    return run_case(argv[1], argv[2], true, false);
 }

@@ -65,3 +65,32 @@ def test_no_gpu_means_loud_failure():
         assert e.code == capi.ERR_DEVICE
     else:
         raise AssertionError("extractor creation must fail without a GPU (no CPU fallback)")
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """orbfe_knn2_sharded_* with a librccl that cannot be loaded (ORBFE_RCCL_LIB forces the name): ORBFE_ERR_DEVICE and the
+    loader's message from every entry point -- the path the bench's fallback and extraction-only installs depend on.  Own
+    process: the binding is resolved once per process."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from orb_slam2_amd import capi
+L = capi.lib()
+assert capi.sharded_available() is False
+msg = L.orbfe_last_error().decode()
+assert "no_such_rccl" in msg, msg
+buf = (C.c_uint8 * 128)()
+assert L.orbfe_knn2_sharded_unique_id(buf) == capi.ERR_DEVICE
+assert "no_such_rccl" in L.orbfe_last_error().decode()
+h = C.c_void_p()
+# a non-null matcher pointer that is never dereferenced: the binding is checked before the matcher is touched
+assert L.orbfe_knn2_sharded_create(C.c_void_p(8), buf, 0, 1, 16, C.byref(h)) == capi.ERR_DEVICE
+assert not h.value
+print("ok")
+""" % str(ROOT)
+    import os
+    env = dict(os.environ, ORBFE_RCCL_LIB="/nonexistent/libno_such_rccl.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

@@ -273,6 +273,65 @@ def test_dense_noise_switches_to_the_large_survivor_list():
             assert np.array_equal(dh[f, :n[f]], dr), (sync, f)
 
 
+def test_overflow_recovery_with_several_batches_queued():
+    """Five asynchronous batches queued back to back (the offline-extraction pattern of bench.py), uniform noise in a frame of
+    the SECOND: orbfe_synchronize runs all five again with the large-list kernel and every output equals the oracle's.  Then
+    the detour ends by itself: after 16 further batches the handle is back on the normal kernel, and ordinary frames stay
+    bit-exact on the way."""
+    torch = pytest.importorskip("torch")
+    w, h = 1491, 344
+    noise = np.random.default_rng(9176).integers(0, 256, (h, w)).astype(np.uint8)
+    o = O.OracleExtractor(100, 2.0, 3, 35, 2)
+    stride = (w + 63) // 64 * 64
+    nb, fpb, cap = 5, 2, 200
+    host = np.zeros((nb, fpb, h, stride), np.uint8)
+    for b in range(nb):
+        for f in range(fpb):
+            host[b, f, :, :w] = synth.textured_image(w, h, synth.BASE_SEED + 20 + 2 * b + f)
+    host[1, 1, :, :w] = noise
+    want = [[o.extract(np.ascontiguousarray(host[b, f, :, :w])) for f in range(fpb)] for b in range(nb)]
+    frames = torch.from_numpy(host).cuda()
+    g = capi.ORBextractor(100, 2.0, 3, 35, 2)
+    assert g.fast_variant() == 1
+    kps = torch.zeros((nb, fpb, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((nb, fpb, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros((nb, fpb), dtype=torch.int32, device="cuda")
+
+    def enqueue(b):
+        g.extract_batch_device(frames[b].data_ptr(), fpb, w, h, stride, stride * h, kps[b].data_ptr(), desc[b].data_ptr(),
+                               cnt[b].data_ptr(), cap, sync=False)
+
+    def check_batch(b):
+        n = cnt[b].cpu().numpy()
+        kh = kps[b].cpu().numpy().view(np.uint8).reshape(fpb, cap, 28)
+        dh = desc[b].cpu().numpy()
+        for f in range(fpb):
+            kr, dr = want[b][f]
+            assert n[f] == len(kr), (b, f)
+            assert np.array_equal(kh[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), kr), (b, f)
+            assert np.array_equal(dh[f, :n[f]], dr), (b, f)
+
+    for b in range(nb):
+        enqueue(b)
+    g.synchronize()                      # status bit 2 -> all five batches again on the large-list kernel
+    assert g.fast_variant() == 2
+    for b in range(nb):
+        check_batch(b)
+    # the detour: 16 batches on the large list, then the normal kernel again
+    for k in range(17):
+        kps.zero_(); cnt.zero_()
+        enqueue(0)
+        g.synchronize()
+        check_batch(0)
+    assert g.fast_variant() == 1
+    # noise again: one rerun, and the next detour lasts twice as long
+    enqueue(0); enqueue(1); enqueue(2)
+    g.synchronize()
+    assert g.fast_variant() == 2
+    for b in range(3):
+        check_batch(b)
+
+
 def test_tiled_descriptor_variant_matches_oracle(monkeypatch):
     """ORBFE_DESCRIBE_TILED=1 selects kp_bucket_kernel + orient_describe_tiled_kernel (keypoints bucketed by 128 x 64 tile, both
     planes staged in LDS, k_describe_tiled.h): keypoints, angles and descriptors bit-exact and in the reference's order on the

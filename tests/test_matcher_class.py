@@ -827,3 +827,43 @@ def test_constants_and_descriptor_distance(tmp_path):
     out = run(tmp_path, 12, [V], P, [1], [0.6, 0])
     assert out[:3].tolist() == [50, 100, 30]
     assert int(out[3]) == O.lib().orc_hamming(O._ptr(V["d"][0], O.u8p), O._ptr(V["d"][1], O.u8p))
+
+
+# ------------------------------------------------------------------ the class from three host threads at once -------------
+def test_three_threads_share_the_grid_pool(tmp_path, monkeypatch):
+    """Tracking, LocalMapping and LoopClosing use ORBmatcher temporaries at the same time (reference src/System.cc:92-102,
+    SURVEY.md section 3.5).  Five of the cases above -- SearchLocalPoints + TrackWithMotionModel (Tracking), Fuse +
+    SearchForTriangulation (LocalMapping), SearchBySim3 (LoopClosing) -- run once alone (checked against the oracle by their
+    own tests, outputs kept), then all at once on a thread each, 12 times over, with frame ids folded onto {0, 1} so that
+    different frames collide on the pool's keys, and ORBFE_GRID_POOL=2 so that leases contend, the pool grows past its size,
+    trims itself and recycles grids.  Every thread must leave exactly what the single-threaded run left."""
+    import shutil
+    me = sys.modules[__name__]
+    cases = []
+    real_run, real_view = me.run, me.view
+
+    def keeping_run(tp, *args, **kw):
+        out = real_run(tp, *args, **kw)
+        k = len(cases)
+        shutil.copy(tp / "world.bin", tmp_path / f"w{k}.bin")
+        shutil.copy(tp / "out.bin", tmp_path / f"ref{k}.bin")
+        cases.append(k)
+        return out
+
+    monkeypatch.setattr(me, "run", keeping_run)
+    monkeypatch.setattr(me, "view", lambda seed, T, frame_id, nodes=None: real_view(seed, T, frame_id % 2, nodes))
+    monkeypatch.setenv("ORBFE_GRID_POOL", "2")
+    for k, call in enumerate([lambda d: test_search_local_points(d, 3.0), lambda d: test_track_with_motion_model(d, "forward", 1),
+                              lambda d: test_fuse_into_keyframe(d), lambda d: test_search_for_triangulation(d, 0, 1),
+                              lambda d: test_search_by_sim3(d)]):
+        d = tmp_path / f"case{k}"
+        d.mkdir()
+        call(d)
+    assert len(cases) == 5
+    argv = [str(EXE), "--concurrent", "12"]
+    for k in cases:
+        argv += [str(tmp_path / f"w{k}.bin"), str(tmp_path / f"mt{k}.bin")]
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in cases:
+        assert (tmp_path / f"mt{k}.bin").read_bytes() == (tmp_path / f"ref{k}.bin").read_bytes(), f"case {k} differs under concurrency"
