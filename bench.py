@@ -40,12 +40,68 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (
 N_UNIQUE = 16                               # distinct synthetic frames, tiled to the batch size
 
 
+def host_cores() -> dict:
+    """The host cores this process may use: the affinity mask, cut by the cgroup CPU quota where one is set (a 1-GPU box shows
+    the whole machine's CPUs in its mask but owns a 16-CPU share of them).  `threads` is what the CPU baselines run on."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    threads = aff if quota is None else max(1, min(aff, int(round(quota))))
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if quota is None and env.isdigit() and 0 < int(env) < threads:
+        threads = int(env)      # no quota visible: the box's own sizing hint (set to its CPU share)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"threads": threads, "affinity_cpus": aff, "cgroup_cpu_quota": quota, "cpu_model": model}
+
+
+def cpu_side(W, H, nfeat, seed_first, budget_s=2.5) -> dict:
+    """The CPU oracle on one of the other configurations: per-frame time on one core and the rate on every core of the box."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as O
+    from orb_slam2_amd import synth
+    hc = host_cores()
+    frames = np.ascontiguousarray(synth.frame_sequence(8, W, H, first=seed_first))
+    ex = O.OracleExtractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH)
+    per = []
+    for rep in range(2):
+        for f in frames:
+            t0 = time.perf_counter()
+            ex.extract(np.ascontiguousarray(f))
+            per.append(time.perf_counter() - t0)
+    per = np.array(per[len(frames):])
+    t1, _ = O.time_extract(frames, nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, hc["threads"], reps=1)
+    reps = int(max(1, min(200, budget_s / max(t1, 1e-3))))
+    t, _ = O.time_extract(frames, nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, hc["threads"], reps=reps)
+    return {"kind": "port", "per_frame_ms_one_core": {"median": round(float(np.median(per)) * 1e3, 3), "mean": round(float(per.mean()) * 1e3, 3)},
+            "frames_per_s_all_cores": round(len(frames) * reps / t, 1), "cores": hc["threads"],
+            "sample": f"{len(frames) * reps} extractions of 8 distinct {W}x{H} frames in {t:.1f} s"}
+
+
 def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
     """Time the CPU oracle (tests/oracle_lib.py -> oracle/liborb_oracle.so) on the box's host cores."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as O
 
-    threads = min(16, len(os.sched_getaffinity(0)))     # a 1-GPU box owns a 16-CPU share
+    hc = host_cores()
+    threads = hc["threads"]                             # every core this box gives the process (count and model in the result)
     t, _ = O.time_extract(frames, NFEATURES, SCALE, NLEVELS, INI_TH, MIN_TH, threads, reps=1)
     per_pass = max(t, 1e-3)
     reps = int(max(1, min(1000, budget_s / per_pass)))
@@ -61,15 +117,8 @@ def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
             ex.extract(np.ascontiguousarray(f))
             per_frame.append(time.perf_counter() - t0)
     per_frame = np.array(per_frame[len(frames):])       # second pass: buffers warm
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": round(n / t, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": model,
+    return {"value": round(n / t, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": hc["cpu_model"],
+            "affinity_cpus": hc["affinity_cpus"], "cgroup_cpu_quota": hc["cgroup_cpu_quota"],
             "per_frame_ms_one_core": {"median": round(float(np.median(per_frame)) * 1e3, 3), "mean": round(float(per_frame.mean()) * 1e3, 3),
                                       "frames": len(per_frame)},
             "sample": f"{n} extractions ({len(frames)} distinct 1241x376 frames x {reps}) in {t:.1f} s, one frame per thread, "
@@ -96,7 +145,7 @@ def latest_pmc():
     return doc, doc.get("csrc_sha256") != csrc_hash()
 
 
-def other_configs(local_rank, dev):
+def other_configs(local_rank, dev, with_cpu=True):
     """Side measurements for BASELINE.json configs[1] (TUM 640x480, per-frame latency), configs[2] (KITTI stereo pair +
     row-band search) and the EuRoC resolution.  Rank 0, one GPU; a few hundred milliseconds each; not part of `value`."""
     import torch
@@ -143,6 +192,9 @@ def other_configs(local_rank, dev):
 
     out["tum_640x480_1000kp"] = batch_fps(640, 480, 1000, 256)
     out["euroc_752x480_1200kp"] = batch_fps(752, 480, 1200, 256)       # Examples/Stereo/EuRoC.yaml:88
+    if with_cpu:
+        out["tum_640x480_1000kp"]["cpu_oracle"] = cpu_side(640, 480, 1000, 900)
+        out["euroc_752x480_1200kp"]["cpu_oracle"] = cpu_side(752, 480, 1200, 900)
     # BASELINE.json configs[1] through the C++ drop-in (include/ORBextractor.h + adapters/ORBextractor_orbfe.cc): wall clock
     # around ORBextractor::operator() on a host image, with and without the mvImagePyramid mirror
     exe = ROOT / "tests" / "cpp" / "adapter_main"
@@ -189,6 +241,27 @@ def other_configs(local_rank, dev):
         "pairs_per_s_sequential": round(1.0 / float(np.median(lat)), 1),
         "left_keypoints": int(n[0]), "right_keypoints": int(n[1]),
         "points_with_depth": int((dep[:int(n[0])] > 0).sum().item())}
+    if with_cpu:
+        # the same pair on the CPU oracle: two extractions + ComputeStereoMatches (src/Frame.cc:466-640), one core; and pairs in
+        # parallel, one pair per core, estimated from the per-pair time (the oracle's stereo step has no threaded driver)
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib as O
+        el, er = (O.OracleExtractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH) for _ in range(2))
+        tp = []
+        for it in range(6):
+            t0 = time.perf_counter()
+            kl_, dl_ = el.extract(left)
+            kr_, dr_ = er.extract(right)
+            t1 = time.perf_counter()
+            O.stereo_full(el, er, kl_, dl_, kr_, dr_, bf, b)
+            t2 = time.perf_counter()
+            if it:
+                tp.append((t2 - t0, t2 - t1))
+        tp = np.array(tp)
+        out["kitti_stereo_pair_1241x376_2000kp"]["cpu_oracle"] = {
+            "kind": "port", "cores": 1, "latency_ms_pair_extract_plus_stereo_matches": round(float(np.median(tp[:, 0])) * 1e3, 3),
+            "of_which_stereo_matches_ms": round(float(np.median(tp[:, 1])) * 1e3, 3),
+            "note": "the reference runs the two extractions on two threads (src/Frame.cc:78-81): halve the extraction part for that"}
     # DBoW2 transform (N2): tree descent of ORB descriptors down a synthetic 10-ary, 6-level vocabulary (the ORBvoc.txt
     # shape: 1.1 M nodes, 10^6 words), one frame's worth and a 512-frame batch
     co, ci, nd, _wi, _w = synth.regular_vocabulary(10, 6, 31337)
@@ -330,7 +403,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per launch (orbfe_extract_batch call)")
+    ap.add_argument("--batch", type=int, default=640,
+                    help="most frames one launch (orbfe_extract_batch call) carries; a rank's block is cut into EQUAL launches of "
+                         "at most this many frames (profiles/r3_launch_curve.json: throughput is flat from ~320 frames per launch "
+                         "up, 568 measured best, and falls below: 284 -> -2 %%, 64 -> -11 %%)")
     ap.add_argument("--total-frames", type=int, default=4541,
                     help="frames per step over ALL ranks, split in contiguous blocks of ceil(total / G) (BASELINE.json configs[3], "
                          "strong scaling); 0: --batch frames per rank and step (weak scaling)")
@@ -381,7 +457,10 @@ def main():
         B = max(min(block, args.total_frames - f_first), 0)          # this rank's frames per step
     else:
         f_first, B = rank * args.batch, args.batch
-    launch = max(1, min(args.batch, max(B, 1)))                      # frames per orbfe_extract_batch call
+    # frames per orbfe_extract_batch call: the block in equal launches (4541 -> 8 x 568, 568 -> 1 x 568), never a full launch
+    # plus a small ragged one (512 + 56 ran the tail at the 64-frame rate)
+    n_launches = max(1, -(-max(B, 1) // max(args.batch, 1)))
+    launch = max(1, -(-max(B, 1) // n_launches))
     stride = (W + 63) // 64 * 64
     uniq = synth.frame_sequence(N_UNIQUE, W, H, first=0)
     uniq_dev = torch.zeros((N_UNIQUE, H, stride), dtype=torch.uint8)
@@ -552,10 +631,10 @@ def main():
         if world > 1 and sharded is None:
             gathered = torch.zeros((world * 3, NQ), dtype=torch.int32, device=cdev)
 
-        def hstep():
+        def hstep(sync=True):
             if sharded is not None:
                 sharded.run(q.data_ptr(), NQ, db.data_ptr(), shard, rank * shard, res[0].data_ptr(), res[1].data_ptr(),
-                            res[2].data_ptr(), sync=True)
+                            res[2].data_ptr(), sync=sync)
                 return None
             if world > 1:
                 qc = q if cdev.type == "cuda" else q.cpu()
@@ -564,7 +643,7 @@ def main():
                     q.copy_(qc)
                 torch.cuda.synchronize()      # the matcher runs on its own non-blocking stream: order it after the broadcast
             m.knn2_device(q.data_ptr(), NQ, db.data_ptr(), shard, res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
-                          idx_base=rank * shard, sync=True)
+                          idx_base=rank * shard, sync=sync or world > 1)
             if world > 1:
                 torch.cuda.synchronize()
                 dist.all_gather_into_tensor(gathered, res if cdev.type == "cuda" else res.cpu())
@@ -572,32 +651,69 @@ def main():
                 return capi.merge_knn2(g[:, 0], g[:, 1], g[:, 2])
             return None
 
-        for _ in range(3):
-            hstep()
-        barrier()
-        h0 = time.perf_counter()
+        def htime(sync, hsteps):
+            """hsteps query batches: with a host synchronisation after every batch (a tracker that needs each answer before it
+            goes on), or queued back to back on the matcher's stream and drained once (an offline job: several query batches
+            in flight, so the exchange of one batch runs under the scan of the next)"""
+            for _ in range(3):
+                hstep(sync)
+            m.synchronize()
+            barrier()
+            h0 = time.perf_counter()
+            for _ in range(hsteps):
+                hstep(sync)
+            m.synchronize()
+            barrier()
+            t = time.perf_counter() - h0
+            if world > 1:
+                tt = torch.tensor([t], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = float(tt.item())
+            return t
+
         hsteps = 10
-        for _ in range(hsteps):
-            hstep()
-        barrier()
-        hdt = time.perf_counter() - h0
-        if world > 1:
-            tt = torch.tensor([hdt], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            hdt = float(tt.item())
+        hdt = htime(True, hsteps)
+        # back to back only where the whole exchange is stream-ordered (one GPU, or RCCL inside the library)
+        hdt_b2b = htime(False, 4 * hsteps) / 4 if (world == 1 or sharded is not None) else None
         pairs = NQ * shard * world * hsteps
-        # integer-VALU roofline of the pair loop: XOR + popcount-accumulate of 8 dwords is 16 VALU instructions per wave and
-        # reference whatever else the kernel does, and a SIMD issues one wave64 VALU instruction per 4 cycles (measured:
-        # SQ_INSTS_VALU x 4 / kernel cycles = 99.6 %, profiles/r1e_pmc_summary.txt): 1024 SIMDs x 2.4 GHz / 4 / 16 x 64 lanes.
-        peak_pairs = world * 1024 * 2.4e9 / 4 / 16 * 64
+        # Integer-VALU roofline of the pair loop, from THIS repository's measurements (no literals):
+        #   ceiling  -- the scan's own instruction pair, v_xor_b32 v, s, v (reference dword from an SGPR: half rate, 4.15 cycles,
+        #               not the 2.7 of the all-VGPR form) feeding v_bcnt_u32_b32 (accumulating), 16 instructions per wave and
+        #               reference, at the cycles per instruction tools/ubench/valu_rates.hip measured for exactly that chain
+        #               (profiles/valu_rates.json, 8 waves per SIMD): 1024 SIMDs x 2.4 GHz x 64 lanes / (16 x cycles)
+        #   achieved -- pairs / time; instructions per pair from SQ_INSTS_VALU of the kNN kernels (profiles/latest_pmc.json,
+        #               hash-checked against the sources like the FAST counters)
+        rates = {}
+        try:
+            rates = json.loads((ROOT / "profiles" / "valu_rates.json").read_text()).get("rates", {})
+        except (OSError, ValueError):
+            pass
+        chain_cyc = rates.get("xor(s)+bcnt chain @8 waves/SIMD")
+        peak_pairs = world * 1024 * 2.4e9 * 64 / (16 * chain_cyc) if chain_cyc else None
+        knn_pmc = (pmc or {}).get("knn2") or {}
+        instr_per_call = (knn_pmc.get("per_call") or {}).get("SQ_INSTS_VALU")
+        instr_per_pair = instr_per_call * 64 / knn_pmc["pairs_per_call"] if instr_per_call else None
+        best = max(pairs / hdt, (pairs / hdt_b2b) if hdt_b2b else 0.0)
         hamming = {"metric": "hamming_pair_distances_per_sec", "value": round(pairs / hdt, 1), "ms_per_query_batch": round(hdt / hsteps * 1e3, 3),
                    "queries": NQ, "database": shard * world, "shards": world,
+                   "host_sync_per_batch": {"pairs_per_s": round(pairs / hdt, 1), "ms_per_query_batch": round(hdt / hsteps * 1e3, 3)},
+                   "back_to_back": None if hdt_b2b is None else {"pairs_per_s": round(pairs / hdt_b2b, 1),
+                                                                 "ms_per_query_batch": round(hdt_b2b / hsteps * 1e3, 3),
+                                                                 "batches_queued": 4 * hsteps},
                    "exchange": "none (one shard)" if world == 1 else ("RCCL inside liborbfe (orbfe_knn2_sharded_run)" if sharded is not None
                                                                       else "host collectives (rehearsal backend) + orbfe_merge_knn2"),
-                   "valu": {"achieved_Tpairs": round(pairs / hdt / 1e12, 3), "peak_Tpairs": round(peak_pairs / 1e12, 3),
-                            "frac": round(pairs / hdt / peak_pairs, 4), "valu_instructions_per_pair": 16.75,
-                            "note": "8 v_xor + 8 v_bcnt_u32_b32 (accumulating) + v_min3/v_min/v_cmp per 4 references; the best/second "
-                                    "selection runs only where a reference can still matter (sample-seeded threshold)"}}
+                   "valu": {"achieved_Tpairs": round(best / 1e12, 3),
+                            "peak_Tpairs": round(peak_pairs / 1e12, 3) if peak_pairs else None,
+                            "frac": round(best / peak_pairs, 4) if peak_pairs else None,
+                            "of": "back_to_back" if hdt_b2b and pairs / hdt_b2b >= pairs / hdt else "host_sync_per_batch",
+                            "ceiling": {"instructions_per_pair": 16, "cycles_per_instruction": chain_cyc,
+                                        "source": "profiles/valu_rates.json: 'xor(s)+bcnt chain @8 waves/SIMD' (tools/ubench/valu_rates.hip, "
+                                                  "k_hamming_chain: the scan's v_xor_b32 v,s,v + v_bcnt_u32_b32 sequence)"},
+                            "valu_instructions_per_pair": round(instr_per_pair, 3) if instr_per_pair else None,
+                            "pmc": {"file": "profiles/latest_pmc.json", "stale": bool(pmc_stale), "calls_profiled": knn_pmc.get("calls_profiled")},
+                            "note": "8 v_xor (SGPR operand) + 8 v_bcnt_u32_b32 (accumulating) per pair + v_min3/v_min/v_cmp per 4 "
+                                    "references + the sample pre-pass and the folds; the best/second selection runs only where a "
+                                    "reference can still matter (sample-seeded threshold)"}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -607,7 +723,7 @@ def main():
             # __builtin_popcount variant of the same best / second-best scan, one block of queries per host thread
             sys.path.insert(0, str(ROOT / "tests"))
             import oracle_lib as O
-            threads = min(16, len(os.sched_getaffinity(0)))
+            threads = host_cores()["threads"]
             db_host = db.cpu().numpy()
             ns = len(db_host)       # 2e9 pairs: a few tenths of a second on the GPU box's 16 host threads
             t_swar = O.time_knn2(q_host, db_host[:ns], threads, swar=True)
@@ -619,7 +735,7 @@ def main():
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = other_configs(local_rank, dev)
+        extras = other_configs(local_rank, dev, with_cpu=not args.no_cpu_baseline)
         if nh == 1 and B > 2 * launch:
             # the same step with its launches dealt round-robin to three handles (three HIP streams): the latency-bound stages of
             # one launch run under the issue-bound stages of another.  Not the headline: the event time around FAST, and with it

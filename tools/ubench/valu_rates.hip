@@ -117,9 +117,45 @@ DEFKERNEL(k_add, A_ADD)
 DEFKERNEL(k_pkmul, A_PKMUL)
 DEFKERNEL(k_fma, A_FMA)
 
+// ---- the Hamming scan's operand shapes (k_match.h: hamming256): the XOR takes the reference dword from an SGPR, the
+// popcount accumulates in a VGPR chain.  k_xor_sgpr: v_xor_b32 v, s, v alone; k_hamming_chain: the scan's own sequence for one
+// reference and eight independent queries-worth of chains -- 8 x (v_xor_b32 t, s, q ; v_bcnt_u32_b32 d, t, d) per chain
+// register, counted as 16 instructions.
+__global__ __launch_bounds__(256) void k_xor_sgpr(unsigned *out, unsigned seed) {
+    unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const unsigned sb = __builtin_amdgcn_readfirstlane(seed * 2654435761u);
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            asm volatile("v_xor_b32 %0, %8, %0\nv_xor_b32 %1, %8, %1\nv_xor_b32 %2, %8, %2\nv_xor_b32 %3, %8, %3\n"
+                         "v_xor_b32 %4, %8, %4\nv_xor_b32 %5, %8, %5\nv_xor_b32 %6, %8, %6\nv_xor_b32 %7, %8, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "s"(sb));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_chain(unsigned *out, unsigned seed) {
+    unsigned q0 = threadIdx.x + seed, q1 = q0 * 3, q2 = q0 * 5, q3 = q0 * 7;
+    unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, t0, t1, t2, t3;
+    const unsigned sb = __builtin_amdgcn_readfirstlane(seed * 2654435761u);
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)   // 8 instructions per statement: 4 XOR + 4 BCNT, the scan's interleaving
+            asm volatile("v_xor_b32 %4, %12, %8\nv_bcnt_u32_b32 %0, %4, %0\nv_xor_b32 %5, %12, %9\nv_bcnt_u32_b32 %1, %5, %1\n"
+                         "v_xor_b32 %6, %12, %10\nv_bcnt_u32_b32 %2, %6, %2\nv_xor_b32 %7, %12, %11\nv_bcnt_u32_b32 %3, %7, %3"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                         : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "s"(sb));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = d0 ^ d1 ^ d2 ^ d3;
+}
+
 typedef void (*kern_t)(unsigned *, unsigned);
 
-int main() {
+int main(int argc, char **argv) {
+    FILE *js = argc > 1 ? fopen(argv[1], "w") : nullptr;   // optional: the table as JSON (bench.py reads profiles/valu_rates.json)
+    if (js) fprintf(js, "{\n \"clock_GHz\": 2.4,\n \"unit\": \"cycles per wave64 instruction per SIMD at the nominal clock\",\n \"rates\": {");
+    bool first = true;
     unsigned *out;
     hipMalloc(&out, 256 * 4 * 16 * 256 * sizeof(unsigned) * 4);
     struct { const char *name; kern_t k; } ks[] = {
@@ -134,7 +170,8 @@ int main() {
         {"v_dot2_u32_u16", k_dot2}, {"v_sub_u32", k_sub}, {"v_lshlrev_b32", k_lshl}, {"v_bfe_u32", k_bfe},
         {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_cvt_f32_ubyte0", k_cvtub}, {"v_pk_max_i16", k_pkmaxi},
         {"v_max3_f32", k_max3f}, {"v_max3_f16", k_max3f16}, {"v_pk_maximum3_f16", k_pkmax3f},
-        {"v_pk_minimum3_f16", k_pkmin3f}, {"v_max3_u16", k_max3u16}, {"v_maximum3_f32", k_maximum3f32}};
+        {"v_pk_minimum3_f16", k_pkmin3f}, {"v_max3_u16", k_max3u16}, {"v_maximum3_f32", k_maximum3f32},
+        {"v_xor_b32 v,s,v", k_xor_sgpr}, {"xor(s)+bcnt chain", k_hamming_chain}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -155,6 +192,14 @@ int main() {
             const double laneOps = instrPerWave * 64.0 * blocks * 4;
             const double cyc = (ms * 1e-3 * 2.4e9) / (instrPerWave * w);
             printf("%-18s %6d %12.2f %14.2f\n", k.name, w, laneOps / (ms * 1e-3) / 1e12, cyc);
+            if (js) {
+                fprintf(js, "%s\n  \"%s @%d waves/SIMD\": %.3f", first ? "" : ",", k.name, w, cyc);
+                first = false;
+            }
         }
+    if (js) {
+        fprintf(js, "\n }\n}\n");
+        fclose(js);
+    }
     return 0;
 }
