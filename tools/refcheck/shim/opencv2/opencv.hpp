@@ -1,0 +1,1 @@
+#include "refcheck_cv.h"
