@@ -23,7 +23,6 @@
 #include "common.h"
 #include "k_blur.h"
 #include "k_describe.h"
-#include "k_describe_tiled.h"
 #include "k_fast.h"
 #include "k_fast_sparse.h"
 #include "k_match.h"
@@ -115,15 +114,10 @@ struct orbfe_extractor {
     std::vector<char> rszWide;          // 0: 8-byte source window, 1: 12-byte window (scale factor ~2), 2: gather kernel
     std::vector<BlurTile> hBlurTiles;
     std::vector<FastTile> hFastTiles;
-    DevBuf dRsz, dBlurTiles, dFastTiles, dDescMask, dDescMaskDw;
+    DevBuf dRsz, dBlurTiles, dFastTiles, dDescMask;
     // per-batch workspace
     DevBuf dPyr, dBlur, dCand, dSel, dSelCount;
-    DevBuf dSorted, dTileTab;           // keypoints bucketed by tile for the tiled descriptor kernel (k_describe_tiled.h)
-    DescTileGeom tileGeom;
-    bool tilesFit = true;
     int numCUs = 256;
-    bool describeTiled = false;         // ORBFE_DESCRIBE_TILED=1: bucketed keypoints + LDS-staged tiles (k_describe_tiled.h); measured equal at 512 frames per
-                                        // launch and slower at 64 (profiles/r2d_describe_tiled_ab.txt), so the untiled kernel stays the default
     // status word, per-level candidate counts and the cell table share one allocation: one memset per batch zeroes them
     DevBuf dCounters;
     int *pStatus = nullptr, *pLevelCount = nullptr;
@@ -423,23 +417,6 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
     g.blurFrameBytes = blurOff;
     g.candFrameCap = candOff;
     g.selFrameCap = selOff;
-    {
-        // tiles of kDtW x kDtH keypoint positions over [19, w - 19) x [19, h - 19) of every level
-        DescTileGeom &tg = e->tileGeom;
-        int base = 0;
-        e->tilesFit = true;
-        for (int l = 0; l < kMaxLevels; l++) {
-            tg.tilesX[l] = 1;
-            tg.tileBase[l] = base;
-            if (l >= g.nlevels) continue;
-            const int tx = (g.lv[l].w - 2 * kEdge + kDtW - 1) / kDtW, ty = (g.lv[l].h - 2 * kEdge + kDtH - 1) / kDtH;
-            tg.tilesX[l] = std::max(tx, 1);
-            const int nT = std::max(tx, 1) * std::max(ty, 1);
-            if (nT > kDtMaxTiles) e->tilesFit = false;
-            base += nT;
-        }
-        for (int l = g.nlevels; l <= kMaxLevels; l++) tg.tileBase[l] = base;
-    }
     HIPCHK(e->dRsz.ensure(e->hRsz.size() * sizeof(RszTab) + 16));
     if (!e->hRsz.empty())
         HIPCHK(hipMemcpyAsync(e->dRsz.p, e->hRsz.data(), e->hRsz.size() * sizeof(RszTab), hipMemcpyHostToDevice, e->stream));
@@ -476,10 +453,6 @@ int ensure_workspace(orbfe_extractor *e, int F) {
     }
     HIPCHK(e->dSel.ensure((size_t)F * g.selFrameCap * sizeof(SelKp)));
     HIPCHK(e->dSelCount.ensure((size_t)F * kMaxLevels * sizeof(int)));
-    if (e->describeTiled && e->tilesFit) {
-        HIPCHK(e->dSorted.ensure((size_t)F * g.selFrameCap * sizeof(SortedKp)));
-        HIPCHK(e->dTileTab.ensure((size_t)F * e->tileGeom.tileBase[g.nlevels] * sizeof(int2)));
-    }
     HIPCHK(e->hStatus.ensure(16));
     return ORBFE_OK;
 }
@@ -781,29 +754,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     // K4 + K6
     if (fork) HIPCHK(hipStreamWaitEvent(st, e->evBlurDone, 0));
     if (prof) HIPCHK(hipEventRecord(e->ev[4], st));
-    if (e->describeTiled && e->tilesFit) {
-        BucketArgs b;
-        b.g = g; b.tg = e->tileGeom;
-        b.sel = (const SelKp *)e->dSel.p;
-        b.selCount = (const int *)e->dSelCount.p;
-        b.sorted = (SortedKp *)e->dSorted.p;
-        b.tileTab = (int2 *)e->dTileTab.p;
-        b.counts = dCounts;
-        hipLaunchKernelGGL(kp_bucket_kernel, dim3(g.nlevels, F), dim3(256), 0, st, b);
-        DescribeTiledArgs a;
-        a.g = g; a.s = src; a.tg = e->tileGeom;
-        a.sorted = (const SortedKp *)e->dSorted.p;
-        a.tileTab = (const int2 *)e->dTileTab.p;
-        a.kps = (KeyPointOut *)dKps;
-        a.desc = dDesc;
-        a.cap = cap;
-        a.nFrames = F;
-        a.maskTab = (const uint4 *)e->dDescMaskDw.p;
-        // persistent workgroups: as many as fit a CU's LDS, a multiple of the 8 XCDs, never more than there are jobs
-        const long jobs = (long)e->tileGeom.tileBase[g.nlevels] * ((F + 7) / 8 * 8);
-        const unsigned groups = (unsigned)std::max(8L, std::min(jobs, (long)e->numCUs * kDtGroupsPerCU) / 8 * 8);
-        hipLaunchKernelGGL(orient_describe_tiled_kernel, dim3(groups), dim3(256), 0, st, a);
-    } else {
+    {
         DescribeArgs a;
         a.g = g; a.s = src;
         a.sel = (const SelKp *)e->dSel.p;
@@ -881,10 +832,6 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         desc_mask_table(e->umax.data(), tab.data());
         er = e->dDescMask.ensure(tab.size() * sizeof(uint2));
         if (er == hipSuccess) er = hipMemcpy(e->dDescMask.p, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice);
-        std::vector<uint2> tabDw((size_t)kDtMaskTabU4 * 2);
-        desc_mask_table_dwords(e->umax.data(), tabDw.data());
-        if (er == hipSuccess) er = e->dDescMaskDw.ensure(tabDw.size() * sizeof(uint2));
-        if (er == hipSuccess) er = hipMemcpy(e->dDescMaskDw.p, tabDw.data(), tabDw.size() * sizeof(uint2), hipMemcpyHostToDevice);
         if (er != hipSuccess) {
             orbfe_extractor_destroy(e);
             return fail(ORBFE_ERR_DEVICE, std::string("mask table: ") + hipGetErrorString(er));
@@ -895,7 +842,6 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->numCUs = cus;
     }
-    if (const char *dt = getenv("ORBFE_DESCRIBE_TILED")) e->describeTiled = atoi(dt) != 0;
     if (const char *fv = getenv("ORBFE_FAST_VARIANT")) e->fastVariant = std::min(std::max(atoi(fv), 0), 2);
     e->fastVariantBase = e->fastVariant;
     *out = e;
@@ -952,8 +898,8 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
     for (int b = 0; b < 2; b++)
         for (hipEvent_t ev : {e->seqEvIn[b], e->seqEvComp[b], e->seqEvOut[b]})
             if (ev) (void)hipEventDestroy(ev);
-    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dDescMask, &e->dDescMaskDw, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
-                      &e->dSelCount, &e->dSorted, &e->dTileTab, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->seqIn[0], &e->seqIn[1], &e->seqKps[0], &e->seqKps[1],
+    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dDescMask, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
+                      &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->seqIn[0], &e->seqIn[1], &e->seqKps[0], &e->seqKps[1],
                       &e->seqDesc[0], &e->seqDesc[1], &e->seqCnt[0], &e->seqCnt[1]})
         b->release();
     for (PinBuf *b : {&e->hImg, &e->hCand, &e->hLevelCount, &e->hCellTab, &e->hSel, &e->hSelCount, &e->hKps, &e->hDesc, &e->hCounts, &e->hStatus, &e->hMirror})

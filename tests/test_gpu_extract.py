@@ -332,46 +332,6 @@ def test_overflow_recovery_with_several_batches_queued():
         check_batch(b)
 
 
-def test_tiled_descriptor_variant_matches_oracle(monkeypatch):
-    """ORBFE_DESCRIBE_TILED=1 selects kp_bucket_kernel + orient_describe_tiled_kernel (keypoints bucketed by 128 x 64 tile, both
-    planes staged in LDS, k_describe_tiled.h): keypoints, angles and descriptors bit-exact and in the reference's order on the
-    three camera configurations, on odd sizes (partial tiles, one-tile levels), on a quota large enough for several staging
-    passes per tile, and through the batched entry point with a keypoint capacity smaller than the frame's count."""
-    torch = pytest.importorskip("torch")
-    monkeypatch.setenv("ORBFE_DESCRIBE_TILED", "1")
-    for cfg in ("kitti", "tum", "euroc"):
-        img, g, o = _pair(cfg, 21)
-        kg, dg = g(img)
-        ko, do = o.extract(img)
-        assert np.array_equal(kg, ko) and np.array_equal(dg, do), cfg
-    for (w, h, nf, sf, nl) in [(401, 301, 500, 1.2, 8), (1920, 1080, 3000, 1.2, 8), (1024, 128, 300, 1.2, 3), (333, 257, 4000, 1.5, 4),
-                               (2560, 720, 2500, 2.0, 4)]:
-        img = synth.textured_image(w, h, synth.BASE_SEED + 177 + w)
-        g, o = capi.ORBextractor(nf, sf, nl, 20, 7), O.OracleExtractor(nf, sf, nl, 20, 7)
-        kg, dg = g(img)
-        ko, do = o.extract(img)
-        assert np.array_equal(kg, ko) and np.array_equal(dg, do), (w, h)
-    w, h, cap = 1241, 376, 1500          # cap below the ~2000 keypoints of a frame: the first cap in reference order are kept
-    stride = 1280
-    host = np.zeros((9, h, stride), np.uint8)
-    for f in range(9):
-        host[f, :, :w] = synth.textured_image(w, h, synth.BASE_SEED + 300 + f)
-    frames = torch.from_numpy(host).cuda()
-    kps = torch.zeros((9, cap, 7), dtype=torch.float32, device="cuda")
-    desc = torch.zeros((9, cap, 32), dtype=torch.uint8, device="cuda")
-    cnt = torch.zeros(9, dtype=torch.int32, device="cuda")
-    g, o = capi.ORBextractor(2000, 1.2, 8, 20, 7), O.OracleExtractor(2000, 1.2, 8, 20, 7)
-    g.extract_batch_device(frames.data_ptr(), 9, w, h, stride, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap)
-    n = cnt.cpu().numpy()
-    kh = kps.cpu().numpy().view(np.uint8).reshape(9, cap, 28)
-    dh = desc.cpu().numpy()
-    for f in range(9):
-        kr, dr = o.extract(np.ascontiguousarray(host[f, :, :w]))
-        assert n[f] == len(kr) and len(kr) > cap
-        assert np.array_equal(kh[f].copy().view(capi.KP_DTYPE).reshape(-1), kr[:cap]), f
-        assert np.array_equal(dh[f], dr[:cap]), f
-
-
 def test_sparse_fast_variant_matches_oracle(monkeypatch):
     """ORBFE_FAST_VARIANT=0 selects fast_cells_sparse_kernel (compass pre-test, score network on the queued candidates only,
     k_fast_sparse.h): stage by stage bit-exact on the three camera configurations, on odd geometries with packed segments
