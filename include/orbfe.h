@@ -133,7 +133,7 @@ int orbfe_debug_stage(orbfe_extractor *e, int frame, int level, int what, void *
  * cos_sin[2*i+1] = b for angles_deg[i].  Host pointers; synchronous.  For the known-answer test over the angles where a
  * faster device routine used to differ from libm (tests/golden/sincos_census.json). */
 int orbfe_debug_rotation(orbfe_extractor *e, const float *angles_deg, int n, float *cos_sin);
-/* The FAST kernel variant the handle's next batch will run: 0 = sparse, 1 = dense (default), 2 = dense with the large per-strip
+/* The FAST kernel variant the handle's next batch will run: 1 = dense (default), 2 = dense with the large per-strip
  * survivor list (entered after an overflow, left again after 16, 32, ... batches).  For the tests of that recovery; no counterpart
  * in the reference. */
 int orbfe_debug_fast_variant(const orbfe_extractor *e);

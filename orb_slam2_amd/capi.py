@@ -254,7 +254,7 @@ class ORBextractor:
         return int(self._L.orbfe_extractor_stream(self._h) or 0)
 
     def fast_variant(self) -> int:
-        """orbfe_debug_fast_variant: 0 sparse, 1 dense, 2 dense with the large survivor list (after an overflow)."""
+        """orbfe_debug_fast_variant: 1 dense, 2 dense with the large survivor list (after an overflow)."""
         return int(self._L.orbfe_debug_fast_variant(self._h))
 
     # ---- mvImagePyramid (include/ORBextractor.h:85)

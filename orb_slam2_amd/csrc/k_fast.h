@@ -172,7 +172,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// ---- the end of a tile, shared by the dense and the sparse kernel: `list` holds the wave's survivor records in row-major
+// ---- the end of a tile: `list` holds the wave's survivor records in row-major
 // order (x = kept scores, one byte per pixel of the lane's dword; y = lane | wave-cell of each of the 4 pixels << 6 | row
 // << 18), cellMax[16] is zero, seg[] describes the tile's segments (first lane, first wave-cell, x and y origin).
 template <int CAP>

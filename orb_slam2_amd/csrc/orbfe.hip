@@ -24,7 +24,6 @@
 #include "k_blur.h"
 #include "k_describe.h"
 #include "k_fast.h"
-#include "k_fast_sparse.h"
 #include "k_match.h"
 #include "k_pyramid.h"
 #include "k_quadtree.h"
@@ -136,9 +135,10 @@ struct orbfe_extractor {
     ImgSrc last{};
     int lastFrames = 0;
     bool overflow = false;
-    // FAST kernel variant: 0 = sparse (k_fast_sparse.h; opt-in through ORBFE_FAST_VARIANT=0, faster only where few pixels
-    // pass the compass test), 1 = dense (k_fast.h, the default), 2 = dense with the large per-wave survivor list.  A tile
-    // that overflows a list of the running variant reports it, and the handle moves to the next variant.
+    // FAST kernel variant: 1 = dense (k_fast.h), 2 = the same kernel with the large per-wave survivor list (one wave per
+    // workgroup).  A tile that overflows the normal list reports it, and the handle takes the large list for a while.  (A sparse
+    // variant -- score network only where a compass pre-test passes -- was built twice and lost at every corner density:
+    // profiles/r2c_fast_sparse_ab.txt, profiles/r3_fast_sparse_ab.txt.)
     int fastVariant = 1;
     int fastVariantBase = 1;            // the variant the handle was created with (ORBFE_FAST_VARIANT)
     // The large-list variant is a detour, not a state: after `demoteAfter` batches on it the handle tries its own variant
@@ -704,11 +704,8 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         }
         if (e->fastVariant >= 2)   // a strip of an earlier batch produced more survivor records than the normal variant holds
             hipLaunchKernelGGL((fast_cells_kernel<kFastListCapMax, 1>), dim3(a.nTiles, F), dim3(64), 0, st, a);
-        else if (e->fastVariant == 1)
-            hipLaunchKernelGGL((fast_cells_kernel<kFastListCap, 4>), dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((fast_cells_sparse_kernel<kFsWaves>), dim3((a.nTiles + kFsWaves - 1) / kFsWaves, F), dim3(64 * kFsWaves),
-                               0, st, a);
+            hipLaunchKernelGGL((fast_cells_kernel<kFastListCap, 4>), dim3((a.nTiles + 3) / 4, F), dim3(256), 0, st, a);
     }
     if (profAny) HIPCHK(hipEventRecord(e->ev[2], st));
     const bool hostTree = quadtree_on_host(e);
@@ -842,7 +839,7 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->numCUs = cus;
     }
-    if (const char *fv = getenv("ORBFE_FAST_VARIANT")) e->fastVariant = std::min(std::max(atoi(fv), 0), 2);
+    if (const char *fv = getenv("ORBFE_FAST_VARIANT")) e->fastVariant = std::min(std::max(atoi(fv), 1), 2);
     e->fastVariantBase = e->fastVariant;
     *out = e;
     return ORBFE_OK;
@@ -933,11 +930,13 @@ void *orbfe_extractor_stream(orbfe_extractor *e) { return e ? (void *)e->stream 
 
 int orbfe_debug_fast_variant(const orbfe_extractor *e) { return e ? e->fastVariant : -1; }
 
+
 // after the stream has drained: fold the device status word into the handle.  The word is sticky on the device (batches
 // enqueued back to back all report into it) and cleared here.  kRerunBigList: a FAST strip overflowed the normal survivor
 // list; the handle has been switched to the large-list kernel and the caller runs the batch again.
 static int eval_status(orbfe_extractor *e) {
     const int st = *(const int *)e->hStatus.p;
+    if (st && getenv("ORBFE_DEBUG_STATUS")) fprintf(stderr, "[orbfe] status word 0x%x (FAST variant %d)\n", st, e->fastVariant);
     if (st) (void)hipMemsetAsync(e->pStatus, 0, sizeof(int), e->stream);
     *(int *)e->hStatus.p = 0;
     if (st & 1) e->overflow = true;
@@ -975,7 +974,7 @@ int orbfe_synchronize(orbfe_extractor *e) {
     for (int attempt = 0; attempt < 2 && rc == kRerunBigList; attempt++) {
         // Asynchronous batches: their arguments are the caller's to keep alive until this call, so they can be run again.  The
         // status word is one per handle: every batch queued since the last synchronisation is run again, in order, on the next
-        // kernel variant (for a sparse handle, ORBFE_FAST_VARIANT=0, a second round reaches the large list).
+        // kernel variant.
         if (pending.empty()) return fail(ORBFE_ERR_CAPACITY, "a FAST strip overflowed its survivor list and no batch is recorded to run again");
         for (const orbfe_extractor::BatchCall &c : pending) {
             rc = run_batch(e, c.imgs, c.F, c.w, c.h, c.stride, c.frameStride, c.kps, c.desc, c.counts, c.cap);

@@ -332,41 +332,6 @@ def test_overflow_recovery_with_several_batches_queued():
         check_batch(b)
 
 
-def test_sparse_fast_variant_matches_oracle(monkeypatch):
-    """ORBFE_FAST_VARIANT=0 selects fast_cells_sparse_kernel (compass pre-test, score network on the queued candidates only,
-    k_fast_sparse.h): stage by stage bit-exact on the three camera configurations, on odd geometries with packed segments
-    and tall cells, on thresholds at the t = 1 edge, and on the uniform-noise frame where its lists overflow and the handle
-    falls back to the dense kernel and then to the dense kernel's large-list variant."""
-    monkeypatch.setenv("ORBFE_FAST_VARIANT", "0")
-    for cfg in ("kitti", "tum", "euroc"):
-        img, g, o = _pair(cfg, 11)
-        kg, dg = g(img)
-        ko, do = o.extract(img)
-        for l in range(8):
-            cg, co = g.debug_stage(l, 2), o.candidates(l)
-            assert cg.shape == co.shape and np.array_equal(cg, co), f"{cfg}: FAST candidates level {l}"
-        assert np.array_equal(kg, ko) and np.array_equal(dg, do), cfg
-    for (w, h, nf, sf, nl, ini, mn) in [(401, 301, 500, 1.2, 8, 20, 7), (1920, 1080, 3000, 1.2, 8, 20, 7), (1024, 128, 300, 1.2, 3, 20, 7),
-                                        (640, 480, 1000, 1.5, 5, 7, 7), (752, 480, 1200, 1.2, 8, 20, 1), (1283, 377, 800, 1.33, 7, 2, 1),
-                                        (1241, 376, 2000, 1.2, 8, 100, 30)]:
-        img = synth.textured_image(w, h, synth.BASE_SEED + 77 + w)
-        g, o = capi.ORBextractor(nf, sf, nl, ini, mn), O.OracleExtractor(nf, sf, nl, ini, mn)
-        kg, dg = g(img)
-        ko, do = o.extract(img)
-        for l in range(nl):
-            assert np.array_equal(g.debug_stage(l, 2), o.candidates(l)), (w, h, l)
-        assert np.array_equal(kg, ko) and np.array_equal(dg, do), (w, h)
-    w, h = 1491, 344
-    img = np.random.default_rng(9176).integers(0, 256, (h, w)).astype(np.uint8)
-    g, o = capi.ORBextractor(100, 2.0, 3, 35, 2), O.OracleExtractor(100, 2.0, 3, 35, 2)
-    kg, dg = g(img)
-    ko, do = o.extract(img)
-    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
-    kg, dg = g(synth.textured_image(w, h, synth.BASE_SEED + 5))       # the same handle afterwards (now on the large-list variant)
-    ko, do = o.extract(synth.textured_image(w, h, synth.BASE_SEED + 5))
-    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
-
-
 @pytest.mark.parametrize("w,h,scale,nlevels", [(1434, 605, 2.0, 4), (1245, 574, 2.0, 3), (1400, 1000, 3.0, 3), (1300, 900, 2.5, 3)])
 def test_resize_ratios_outside_the_register_windows(w, h, scale, nlevels):
     """Level sizes are rounded, so a scale factor of 2 can give a level ratio slightly above 2 (1434 -> 717 -> 358); those

@@ -36,6 +36,6 @@ n = cnt.cpu().numpy()
 crc = 0
 for f in range(min(B, 8)):      # output checksum of the distinct frames: A/B variants must print the same value
     crc = zlib.crc32(desc[f, :n[f]].cpu().numpy().tobytes(), zlib.crc32(kps[f, :n[f]].cpu().numpy().tobytes(), crc))
-print("crc %08x" % crc, end=" ")
+print("crc %08x" % crc, "variant", ex.fast_variant(), end=" ")
 print(str(capi.LIB_PATH).split("/")[-1], {k: round(v / steps, 4) for k, v in p["stage_ms"].items()}, "sum",
       round(sum(p["stage_ms"].values()) / steps, 4), "kps/frame", p["keypoints"] / p["frames"])
