@@ -100,6 +100,14 @@ struct orbfe_extractor {
     // side stream: the blur runs here while the (latency-bound, 2 workgroups per CU) quadtree runs on `stream`
     hipStream_t stream2 = nullptr;
     hipEvent_t evFastDone = nullptr, evBlurDone = nullptr;
+    // pyramid stream: with asynchronous batches queued back to back, the pyramid of batch k+1 (seven dependent, latency-bound
+    // launches) runs on its own stream beside the quadtree / blur / descriptors of batch k -- never beside a FAST kernel (it
+    // starts after FAST of batch k and FAST of batch k+1 waits for it).  Two pyramid buffers alternate.
+    hipStream_t streamPyr = nullptr;
+    hipEvent_t evPyrDone = nullptr, evDescDone[2] = {nullptr, nullptr};
+    bool pyrBufBusy[2] = {false, false}, fastRecorded = false;
+    int pyrFlip = 0;
+    bool overlapPyr = true;             // ORBFE_OVERLAP_PYRAMID
     bool overlap = true;
     // constructor tables (reference src/ORBextractor.cc:415-469)
     double scaleFactor = 1.0;
@@ -115,7 +123,7 @@ struct orbfe_extractor {
     std::vector<FastTile> hFastTiles;
     DevBuf dRsz, dBlurTiles, dFastTiles, dDescMask;
     // per-batch workspace
-    DevBuf dPyr, dBlur, dCand, dSel, dSelCount;
+    DevBuf dPyr, dPyr2, dBlur, dCand, dSel, dSelCount;
     int numCUs = 256;
     // status word, per-level candidate counts and the cell table share one allocation: one memset per batch zeroes them
     DevBuf dCounters;
@@ -431,9 +439,10 @@ int build_geometry(orbfe_extractor *e, int w, int h) {
     return ORBFE_OK;
 }
 
-int ensure_workspace(orbfe_extractor *e, int F) {
+int ensure_workspace(orbfe_extractor *e, int F, bool twoPyramids) {
     const Geom &g = e->g;
     HIPCHK(e->dPyr.ensure((size_t)F * g.pyrFrameBytes));
+    if (twoPyramids) HIPCHK(e->dPyr2.ensure((size_t)F * g.pyrFrameBytes));
     HIPCHK(e->dBlur.ensure((size_t)F * g.blurFrameBytes));
     HIPCHK(e->dCand.ensure((size_t)F * g.candFrameCap * sizeof(Cand)));
     {
@@ -624,18 +633,22 @@ int prof_acquire(orbfe_extractor *e, int F, orbfe_extractor::ProfSet **out) {
 
 // The pipeline for F frames resident on the device.  Outputs on the device.
 int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int stride, size_t frameStride,
-              orbfe_keypoint *dKps, uint8_t *dDesc, int32_t *dCounts, int cap) {
+              orbfe_keypoint *dKps, uint8_t *dDesc, int32_t *dCounts, int cap, bool queued = false) {
     int rc = build_geometry(e, w, h);
     if (rc) return rc;
-    rc = ensure_workspace(e, F);
+    // `queued`: an asynchronous orbfe_extract_batch call whose input frames are ready before the call (no copy of this library
+    // precedes it on the stream) -- its pyramid may run ahead on the pyramid stream
+    const bool forkPyr = queued && e->overlap && e->overlapPyr && e->profiling != 1 && !quadtree_on_host(e) && e->g.nlevels > 1;
+    rc = ensure_workspace(e, F, forkPyr);
     if (rc) return rc;
     const Geom &g = e->g;
     hipStream_t st = e->stream;
+    const int pb = forkPyr ? (e->pyrFlip ^= 1) : 0;
     ImgSrc src;
     src.img0 = dImgs;
     src.pitch0 = stride;
     src.frameStride0 = frameStride;
-    src.pyr = (uint8_t *)e->dPyr.p;
+    src.pyr = (uint8_t *)(pb ? e->dPyr2.p : e->dPyr.p);
     src.blur = (uint8_t *)e->dBlur.p;
     e->last = src;
     e->lastFrames = F;
@@ -651,6 +664,14 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         if (prof) HIPCHK(hipEventRecord(e->ev[0], st));
     }
     // K1: pyramid, level by level (level l reads level l-1)
+    hipStream_t spyr = forkPyr ? e->streamPyr : st;
+    if (forkPyr) {
+        if (e->fastRecorded) HIPCHK(hipStreamWaitEvent(spyr, e->evFastDone, 0));        // after the previous batch's FAST kernel
+        if (e->pyrBufBusy[pb]) HIPCHK(hipStreamWaitEvent(spyr, e->evDescDone[pb], 0));  // the buffer's last reader has finished
+    } else if (e->pyrBufBusy[0]) {
+        // a batch that does not fork writes buffer 0 on the main stream: stream order already puts it behind every earlier batch
+        e->pyrBufBusy[0] = false;
+    }
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom &L = g.lv[l], &P = g.lv[l - 1];
         ResizeArgs a;
@@ -669,11 +690,15 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         a.rows = e->rszRows[l];
         a.nRowBlocks = (L.h + a.rows - 1) / a.rows;
         if (e->rszWide[l] == 2)
-            hipLaunchKernelGGL(pyr_resize_generic_kernel, dim3((L.w + 1023) / 1024, L.h, F), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(pyr_resize_generic_kernel, dim3((L.w + 1023) / 1024, L.h, F), dim3(256), 0, spyr, a);
         else if (e->rszWide[l])
-            hipLaunchKernelGGL(pyr_resize_kernel<true>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(pyr_resize_kernel<true>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, spyr, a);
         else
-            hipLaunchKernelGGL(pyr_resize_kernel<false>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(pyr_resize_kernel<false>, dim3((a.nStrips * a.nRowBlocks + 3) / 4, F), dim3(256), 0, spyr, a);
+    }
+    if (forkPyr) {
+        HIPCHK(hipEventRecord(e->evPyrDone, spyr));
+        HIPCHK(hipStreamWaitEvent(st, e->evPyrDone, 0));
     }
     // K3: FAST over every cell of every level
     // (the status word in the first 64 bytes stays: it collects over batches until the host has read it)
@@ -717,6 +742,7 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
     hipStream_t sb = fork ? e->stream2 : st;
     if (fork) {
         HIPCHK(hipEventRecord(e->evFastDone, st));
+        e->fastRecorded = true;
         HIPCHK(hipStreamWaitEvent(sb, e->evFastDone, 0));
     }
     hipLaunchKernelGGL(gauss7_kernel, dim3(((unsigned)e->hBlurTiles.size() + 3) / 4, F), dim3(256), 0, sb, g, src,
@@ -767,6 +793,10 @@ int run_batch(orbfe_extractor *e, const uint8_t *dImgs, int F, int w, int h, int
         hipLaunchKernelGGL(orient_describe_kernel, dim3((unsigned)a.groupsPerFrame * ((F + 7) / 8 * 8)), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
+    if (forkPyr) {   // the pyramid buffer's last reader: the moments of the descriptor kernel
+        HIPCHK(hipEventRecord(e->evDescDone[pb], st));
+        e->pyrBufBusy[pb] = true;
+    }
     if (profAny) {
         if (prof) HIPCHK(hipEventRecord(e->ev[5], st));
         ps->hostTree = hostTree;
@@ -817,8 +847,12 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         return fail(ORBFE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(er));
     }
     er = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipStreamCreateWithFlags(&e->streamPyr, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evFastDone, hipEventDisableTiming);
     if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evBlurDone, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evPyrDone, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evDescDone[0], hipEventDisableTiming);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&e->evDescDone[1], hipEventDisableTiming);
     if (er != hipSuccess) {
         orbfe_extractor_destroy(e);
         return fail(ORBFE_ERR_DEVICE, std::string("side stream: ") + hipGetErrorString(er));
@@ -835,6 +869,7 @@ int orbfe_extractor_create(const orbfe_params *params, int device, orbfe_extract
         }
     }
     if (const char *ov = getenv("ORBFE_OVERLAP")) e->overlap = atoi(ov) != 0;
+    if (const char *ov = getenv("ORBFE_OVERLAP_PYRAMID")) e->overlapPyr = atoi(ov) != 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->numCUs = cus;
@@ -880,8 +915,12 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
         (void)hipStreamSynchronize(e->stream2);
         (void)hipStreamDestroy(e->stream2);
     }
-    if (e->evFastDone) (void)hipEventDestroy(e->evFastDone);
-    if (e->evBlurDone) (void)hipEventDestroy(e->evBlurDone);
+    if (e->streamPyr) {
+        (void)hipStreamSynchronize(e->streamPyr);
+        (void)hipStreamDestroy(e->streamPyr);
+    }
+    for (hipEvent_t ev : {e->evFastDone, e->evBlurDone, e->evPyrDone, e->evDescDone[0], e->evDescDone[1]})
+        if (ev) (void)hipEventDestroy(ev);
     for (auto &p : e->profPool) {
         for (auto &ev : p.ev)
             if (ev) (void)hipEventDestroy(ev);
@@ -895,7 +934,7 @@ int orbfe_extractor_destroy(orbfe_extractor *e) {
     for (int b = 0; b < 2; b++)
         for (hipEvent_t ev : {e->seqEvIn[b], e->seqEvComp[b], e->seqEvOut[b]})
             if (ev) (void)hipEventDestroy(ev);
-    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dDescMask, &e->dPyr, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
+    for (DevBuf *b : {&e->dRsz, &e->dBlurTiles, &e->dFastTiles, &e->dDescMask, &e->dPyr, &e->dPyr2, &e->dBlur, &e->dCand, &e->dCounters, &e->dSel,
                       &e->dSelCount, &e->dImg, &e->dKps, &e->dDesc, &e->dCounts, &e->seqIn[0], &e->seqIn[1], &e->seqKps[0], &e->seqKps[1],
                       &e->seqDesc[0], &e->seqDesc[1], &e->seqCnt[0], &e->seqCnt[1]})
         b->release();
@@ -1002,7 +1041,7 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
         frame_stride < (size_t)stride * h)
         return fail(ORBFE_ERR_ARG, "dev_imgs, stride and frame_stride must be multiples of 16 (stride >= w)");
     HIPCHK(hipSetDevice(e->device));
-    int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap);
+    int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap, sync == 0);
     if (rc) return rc;
     e->inFlight.push_back({dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap});
     e->batchesInFlight++;
