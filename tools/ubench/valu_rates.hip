@@ -150,6 +150,23 @@ __global__ __launch_bounds__(256) void k_hamming_chain(unsigned *out, unsigned s
     out[blockIdx.x * 256 + threadIdx.x] = d0 ^ d1 ^ d2 ^ d3;
 }
 
+// the same chain with the reference dword in a VGPR (as it would arrive from an LDS broadcast read): v_xor_b32 v, v, v is full rate
+__global__ __launch_bounds__(256) void k_hamming_chain_vgpr(unsigned *out, unsigned seed) {
+    unsigned q0 = threadIdx.x + seed, q1 = q0 * 3, q2 = q0 * 5, q3 = q0 * 7;
+    unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, t0, t1, t2, t3;
+    unsigned rv = seed * 2654435761u + (threadIdx.x >> 8);   // uniform value, but the compiler keeps it in a VGPR
+    asm volatile("" : "+v"(rv));
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            asm volatile("v_xor_b32 %4, %12, %8\nv_bcnt_u32_b32 %0, %4, %0\nv_xor_b32 %5, %12, %9\nv_bcnt_u32_b32 %1, %5, %1\n"
+                         "v_xor_b32 %6, %12, %10\nv_bcnt_u32_b32 %2, %6, %2\nv_xor_b32 %7, %12, %11\nv_bcnt_u32_b32 %3, %7, %3"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                         : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(rv));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = d0 ^ d1 ^ d2 ^ d3;
+}
+
 typedef void (*kern_t)(unsigned *, unsigned);
 
 int main(int argc, char **argv) {
@@ -171,7 +188,8 @@ int main(int argc, char **argv) {
         {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_cvt_f32_ubyte0", k_cvtub}, {"v_pk_max_i16", k_pkmaxi},
         {"v_max3_f32", k_max3f}, {"v_max3_f16", k_max3f16}, {"v_pk_maximum3_f16", k_pkmax3f},
         {"v_pk_minimum3_f16", k_pkmin3f}, {"v_max3_u16", k_max3u16}, {"v_maximum3_f32", k_maximum3f32},
-        {"v_xor_b32 v,s,v", k_xor_sgpr}, {"xor(s)+bcnt chain", k_hamming_chain}};
+        {"v_xor_b32 v,s,v", k_xor_sgpr}, {"xor(s)+bcnt chain", k_hamming_chain},
+        {"xor(v)+bcnt chain", k_hamming_chain_vgpr}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
