@@ -182,6 +182,7 @@ struct orbfe_extractor {
     long candTotal = 0, kpTotal = 0;
 };
 
+constexpr size_t kMaxQueuedBatches = 4096;
 constexpr int kRerunBigList = 1;   // internal: eval_status asks for the batch to be run again (next FAST kernel variant)
 static int fetch_status(orbfe_extractor *e);
 
@@ -1041,6 +1042,12 @@ int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frame
         frame_stride < (size_t)stride * h)
         return fail(ORBFE_ERR_ARG, "dev_imgs, stride and frame_stride must be multiples of 16 (stride >= w)");
     HIPCHK(hipSetDevice(e->device));
+    // the record of queued calls (kept for the overflow rerun) is bounded: a caller that never synchronises gets a
+    // synchronisation from the library every kMaxQueuedBatches calls, with the usual status handling
+    if (e->inFlight.size() >= kMaxQueuedBatches) {
+        const int rc0 = orbfe_synchronize(e);
+        if (rc0) return rc0;
+    }
     int rc = run_batch(e, dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap, sync == 0);
     if (rc) return rc;
     e->inFlight.push_back({dev_imgs, n_frames, w, h, stride, frame_stride, dev_kps, dev_desc, dev_counts, cap});

@@ -332,6 +332,41 @@ def test_overflow_recovery_with_several_batches_queued():
         check_batch(b)
 
 
+def test_queued_batches_of_changing_frame_count_and_image_size():
+    """Asynchronous batches queued back to back whose frame count grows (the workspace is re-allocated with earlier batches
+    still in flight) and whose image size changes (the level geometry and its device tables are rebuilt in between): after
+    one orbfe_synchronize every batch equals the oracle, frame by frame."""
+    torch = pytest.importorskip("torch")
+    o = O.OracleExtractor(300, 1.2, 5, 20, 7)
+    g = capi.ORBextractor(300, 1.2, 5, 20, 7)
+    cap = 400
+    shapes = [(2, 320, 240), (7, 320, 240), (3, 411, 233), (1, 320, 240), (12, 411, 233), (4, 640, 200)]
+    held = []
+    for b, (F, w, h) in enumerate(shapes):
+        stride = (w + 63) // 64 * 64
+        host = np.zeros((F, h, stride), np.uint8)
+        for f in range(F):
+            host[f, :, :w] = synth.textured_image(w, h, synth.BASE_SEED + 400 + 16 * b + f)
+        frames = torch.from_numpy(host).cuda()
+        kps = torch.zeros((F, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros((F,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g.extract_batch_device(frames.data_ptr(), F, w, h, stride, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
+                               cap, sync=False)
+        held.append((host, frames, kps, desc, cnt))
+    g.synchronize()
+    for (F, w, h), (host, _frames, kps, desc, cnt) in zip(shapes, held):
+        n = cnt.cpu().numpy()
+        kh = kps.cpu().numpy().view(np.uint8).reshape(F, cap, 28)
+        dh = desc.cpu().numpy()
+        for f in range(F):
+            kr, dr = o.extract(np.ascontiguousarray(host[f, :, :w]))
+            assert n[f] == len(kr) and len(kr) > 50, (F, w, h, f)
+            assert np.array_equal(kh[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), kr), (F, w, h, f)
+            assert np.array_equal(dh[f, :n[f]], dr), (F, w, h, f)
+
+
 @pytest.mark.parametrize("w,h,scale,nlevels", [(1434, 605, 2.0, 4), (1245, 574, 2.0, 3), (1400, 1000, 3.0, 3), (1300, 900, 2.5, 3)])
 def test_resize_ratios_outside_the_register_windows(w, h, scale, nlevels):
     """Level sizes are rounded, so a scale factor of 2 can give a level ratio slightly above 2 (1434 -> 717 -> 358); those
