@@ -2,7 +2,11 @@
 """FAST stage time of the dense kernel (ORBFE_FAST_VARIANT=1) against the sparse kernel (=0, all levels) over frames of
 different corner density: KITTI-size synthetic frames with `shapes_per_mpx` random shapes (6500 = the bench's frames), 256 frames
 per launch.  One process per (variant, density) because the variant is fixed when the extractor is created.
-usage: python tools/fast_density_sweep.py           (drives itself through subprocesses; run on the GPU box)"""
+usage: python tools/fast_density_sweep.py           (drives itself through subprocesses; run on the GPU box)
+
+Record of how the density rows of profiles/r3_fast_sparse_ab.txt were made.  The sparse kernel has since left the build
+(source: profiles/r3_fast_sparse_kernel.h.txt, host side: profiles/r3_fast_sparse_host.patch): on the present library
+ORBFE_FAST_VARIANT is clamped to 1..2, so the "sparse" rows would repeat the dense kernel unless that patch is applied."""
 import json
 import os
 import subprocess
