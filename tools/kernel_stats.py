@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Per-kernel statistics from a rocprofv3 --kernel-trace database (rocpd, *_results.db), grouped by kernel name AND
-launch grid, so the launches of bench.py's timed region (512 frames each) stand apart from its side measurements.
+"""Per-kernel statistics from a rocprofv3 --kernel-trace run, grouped by kernel name AND launch grid, so the launches of
+bench.py's timed region (568 frames each) stand apart from its side measurements.  Input: the rocpd database
+(*_results.db, rocprofv3's default output) or the CSV trace (*_kernel_trace.csv, --output-format csv).
 
-usage: python tools/kernel_stats.py gpurun_out/<run>/prof/<name>_results.db > profiles/<round>_bench_kernel_stats.csv
+usage: python tools/kernel_stats.py gpurun_out/<run>/<name>_results.db | <name>_kernel_trace.csv > profiles/<round>_bench_kernel_stats.csv
 """
 import csv
 import math
@@ -11,10 +12,15 @@ import sys
 
 
 def main(path):
-    db = sqlite3.connect(path)
-    rows = db.execute(
-        "SELECT S.display_name, K.grid_size_x, K.grid_size_y, K.end - K.start "
-        "FROM rocpd_kernel_dispatch K JOIN rocpd_info_kernel_symbol S ON S.id = K.kernel_id AND S.guid = K.guid").fetchall()
+    if path.endswith(".csv"):
+        with open(path, newline="") as fh:
+            rows = [(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                    for r in csv.DictReader(fh)]
+    else:
+        db = sqlite3.connect(path)
+        rows = db.execute(
+            "SELECT S.display_name, K.grid_size_x, K.grid_size_y, K.end - K.start "
+            "FROM rocpd_kernel_dispatch K JOIN rocpd_info_kernel_symbol S ON S.id = K.kernel_id AND S.guid = K.guid").fetchall()
     groups = {}
     for name, gx, gy, ns in rows:
         groups.setdefault((name, gx, gy), []).append(ns)
