@@ -1,4 +1,6 @@
 """GPU parity of the Hamming matching entry points against the oracle (bit-exact: distances and indices are integers)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -33,6 +35,41 @@ def test_knn2_matches_oracle(nq, nr):
     ref = O.knn2(q, db)
     for g, r, name in zip(got, ref, ("best_dist", "best_idx", "second_dist")):
         assert np.array_equal(g, r), name
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("ORBFE_MATCH_FUZZ_CASES", "12"))))
+def test_knn2_fuzz(case):
+    """Seeded random shapes on both sides of the seeded-scan threshold (32 768 references), with descriptor statistics that
+    force ties: a small alphabet of rows (many equal distances, duplicates everywhere), sparse rows (few set bits, distances
+    bunched near zero), or uniform rows with planted near-duplicates.  Best distance, best index (first minimum) and second
+    distance equal the oracle's for every query."""
+    rng = np.random.default_rng(4000 + case)
+    nr = int(np.exp(rng.uniform(0.0, np.log(150000.0)))) if case % 2 else int(rng.integers(20000, 150001))
+    nq = int(rng.integers(1, min(3000, max(2, 150_000_000 // max(nr, 1))) + 1))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:                                     # small alphabet: rows repeat, distances tie
+        alpha = synth.random_descriptors(int(rng.integers(2, 40)), 5000 + case)
+        db = alpha[rng.integers(0, len(alpha), nr)]
+        q = alpha[rng.integers(0, len(alpha), nq)].copy()
+        flip = rng.integers(0, 256, nq)
+        q[np.arange(nq), flip >> 3] ^= (1 << (flip & 7)).astype(np.uint8)
+    elif kind == 1:                                   # sparse rows
+        db = np.zeros((nr, 32), np.uint8)
+        q = np.zeros((nq, 32), np.uint8)
+        for a in (db, q):
+            for _ in range(int(rng.integers(0, 6))):
+                bit = rng.integers(0, 256, len(a))
+                a[np.arange(len(a)), bit >> 3] |= (1 << (bit & 7)).astype(np.uint8)
+    else:
+        db = synth.random_descriptors(nr, 6000 + case)
+        q = synth.planted_queries(db, nq, 7000 + case, planted_frac=0.3 if nq >= 10 else 0.0)
+    idx_base = int(rng.integers(0, 1 << 20)) if case % 3 == 0 else 0
+    m = capi.ORBmatcher()
+    got = _knn2(m, np.ascontiguousarray(q), np.ascontiguousarray(db), idx_base=idx_base)
+    ref = O.knn2(np.ascontiguousarray(q), np.ascontiguousarray(db))
+    assert np.array_equal(got[0], ref[0]), (case, nq, nr, kind, "best_dist")
+    assert np.array_equal(got[1], np.where(ref[1] >= 0, ref[1] + idx_base, -1)), (case, nq, nr, kind, "best_idx")
+    assert np.array_equal(got[2], ref[2]), (case, nq, nr, kind, "second_dist")
 
 
 def test_knn2_filtered_scan_matches_oracle():
@@ -428,6 +465,78 @@ def test_search_by_bow_matches_oracle(n1, n2, nn):
         assert np.array_equal(got, ref), (md, ratio)
         total += int((ref >= 0).sum())
     assert total > 20
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("ORBFE_MATCH_FUZZ_CASES", "12"))))
+def test_matcher_fuzz(case):
+    """Seeded random shapes for the other matching entry points, in turn: SearchByBoW node lists, candidate-list argmin,
+    DBoW2 descent over random trees, and the full stereo matcher on a random pair of random size.  Bit-exact against the
+    oracle every time."""
+    rng = np.random.default_rng(8000 + case)
+    m = capi.ORBmatcher()
+    which = case % 4
+    if which == 0:
+        n1, n2, nn = int(rng.integers(1, 2500)), int(rng.integers(1, 5000)), int(np.exp(rng.uniform(0, np.log(2000))))
+        d1, d2, (off1, idx1), (off2, idx2) = _bow_case(rng, n1, n2, nn, noise_bits=int(rng.integers(1, 90)), shuffle=bool(case & 4))
+        v1 = (rng.uniform(size=n1) < 0.85).astype(np.uint8) if case & 8 else None
+        b2 = (rng.uniform(size=n2) < 0.1).astype(np.uint8) if case & 16 else None
+        md, ratio = int(rng.integers(20, 120)), float(rng.choice([0.6, 0.7, 0.75, 0.9, 1.0]))
+        got = m.search_by_bow(d1, v1, d2, b2, off1, idx1, off2, idx2, md, ratio)
+        ref = O.search_by_bow(d1, v1, d2, b2, off1, idx1, off2, idx2, md, ratio)
+        assert np.array_equal(got, ref), (case, n1, n2, nn, md, ratio)
+    elif which == 1:
+        nr, nq = int(rng.integers(1, 6000)), int(rng.integers(1, 4000))
+        r = synth.random_descriptors(nr, 8100 + case)
+        q = synth.planted_queries(r, nq, 8200 + case, planted_frac=0.5 if nq >= 10 else 0.0)
+        counts = rng.integers(0, int(rng.integers(1, 200)), nq)
+        counts[rng.uniform(size=nq) < 0.1] = 0
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        idx = rng.integers(0, nr, off[-1]).astype(np.int32)
+        dq, dr, doff, didx = _dev(q), _dev(r), _dev(off), _dev(idx if len(idx) else np.zeros(1, np.int32))
+        bd, bi, sd = (torch.zeros(nq, dtype=torch.int32, device="cuda") for _ in range(3))
+        m.csr_device(dq.data_ptr(), nq, dr.data_ptr(), nr, doff.data_ptr(), didx.data_ptr(), bd.data_ptr(), bi.data_ptr(), sd.data_ptr())
+        ref = O.match_csr(q, r, off, idx)
+        for g, rr, name in zip((bd, bi, sd), ref, ("best_dist", "best_idx", "second_dist")):
+            assert np.array_equal(g.cpu().numpy(), rr), (case, nq, nr, name)
+    elif which == 2:
+        k, L = int(rng.integers(2, 11)), int(rng.integers(1, 6))
+        while k ** L > 60000:
+            L -= 1
+        levelsup = int(rng.integers(0, L + 2))
+        co, ci, nd, _wi, _w = synth.random_vocabulary(k, L, 8300 + case, irregular=bool(case & 4))
+        n = int(rng.integers(1, 4000))
+        f = synth.random_descriptors(n, 8400 + case)
+        f[: n // 5] = nd[rng.integers(0, len(nd), n // 5)]            # features that sit exactly on nodes
+        ref_leaf, ref_nid = O.bow_descend(co, ci, nd, L, f, levelsup)
+        voc = capi.Vocabulary(co, ci, nd, L)
+        df = _dev(f)
+        leaf = torch.zeros(n, dtype=torch.int32, device="cuda")
+        nid = torch.zeros(n, dtype=torch.int32, device="cuda")
+        m.bow_transform_device(voc, df.data_ptr(), n, levelsup, leaf.data_ptr(), nid.data_ptr())
+        assert np.array_equal(leaf.cpu().numpy(), ref_leaf), (case, k, L, levelsup, n)
+        assert np.array_equal(nid.cpu().numpy(), ref_nid), (case, k, L, levelsup, n)
+    else:
+        W, H = int(rng.integers(320, 1300)), int(rng.integers(240, 500))
+        nfeat = int(rng.choice([300, 1000, 2000]))
+        left, right = synth.stereo_pair(W, H, synth.BASE_SEED + 3000 + case)
+        ol, orr = O.OracleExtractor(nfeat, 1.2, 8, 20, 7), O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+        kol, dol = ol.extract(left)
+        kor, dor = orr.extract(right)
+        bf = float(rng.uniform(30.0, 400.0))
+        b = float(rng.uniform(0.05, 0.6))
+        ref_ur, ref_dep = O.stereo_full(ol, orr, kol, dol, kor, dor, bf, b)
+        gl, gr = capi.ORBextractor(nfeat, 1.2, 8, 20, 7), capi.ORBextractor(nfeat, 1.2, 8, 20, 7)
+        kl, dl = gl(left)
+        kr, dr = gr(right)
+        assert np.array_equal(kl, kol) and np.array_equal(dl, dol) and np.array_equal(kr, kor) and np.array_equal(dr, dor)
+        dkl, dkr = _dev(kl.view(np.uint8).reshape(-1, 28)), _dev(kr.view(np.uint8).reshape(-1, 28))
+        ddl, ddr = _dev(dl), _dev(dr)
+        ur = torch.zeros(len(kl), dtype=torch.float32, device="cuda")
+        dep = torch.zeros(len(kl), dtype=torch.float32, device="cuda")
+        m.stereo_match_device(gl, 0, gr, 0, dkl.data_ptr(), ddl.data_ptr(), len(kl), dkr.data_ptr(), ddr.data_ptr(), len(kr),
+                              bf, b, ur.data_ptr(), dep.data_ptr())
+        assert np.array_equal(ur.cpu().numpy().view(np.uint32), ref_ur.view(np.uint32)), (case, W, H, nfeat, bf, b)
+        assert np.array_equal(dep.cpu().numpy().view(np.uint32), ref_dep.view(np.uint32)), (case, W, H, nfeat, bf, b)
 
 
 def test_search_by_bow_argument_errors():
