@@ -15,6 +15,10 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+# ORBFE_CLASS_SEED shifts every generator seed of this file: the default suite runs seed 0, a soak (tools/class_soak.sh)
+# runs others; the "this case is not vacuous" counts are tuned for seed 0 and only asserted there (`assert SEED0 or ...`)
+SEED0 = 1000003 * int(os.environ.get("ORBFE_CLASS_SEED", "0"))
+
 ROOT = Path(__file__).resolve().parent.parent
 CPP_BIN = Path(os.environ.get("ORBFE_TEST_BIN_DIR", ROOT / "tests" / "cpp"))   # tools/run_asan.sh points this at tests/cpp/_asan
 sys.path.insert(0, str(ROOT))
@@ -40,7 +44,7 @@ def frame(seed):
     if seed not in _frames:
         img = synth.textured_image(W, H, synth.BASE_SEED + seed)
         k, d = O.OracleExtractor(2000, 1.2, 8, 20, 7).extract(img)
-        rng = np.random.default_rng(seed)
+        rng = np.random.default_rng(SEED0 + seed)
         n = len(k)
         ur = np.where(rng.uniform(size=n) < 0.5, k["x"] - rng.uniform(1, 60, n), -1).astype(np.float32)
         _frames[seed] = dict(kx=k["x"].copy(), ky=k["y"].copy(), oct=k["octave"].astype(np.int32), ang=k["angle"].copy(), d=d.copy(),
@@ -99,7 +103,7 @@ def first_min(F, cand, q):
 
 def test_oracle_sim3_projection_and_relocalization_vs_numpy():
     F = frame(11)
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(SEED0 + 1)
     P = points(F, rng, 2600, 4.0)
     g = grid(F)
     occ = (rng.uniform(size=F["n"]) < 0.1).astype(np.uint8)
@@ -139,12 +143,12 @@ def test_oracle_sim3_projection_and_relocalization_vs_numpy():
             want[dropped] = -1
             blocked[dropped] = False
         assert np.array_equal(assigned, want) and n == (want >= 0).sum() and np.array_equal(occ_after.astype(bool), blocked)
-        assert n > 800 and (not check or n < before)
+        assert SEED0 or (n > 800 and (not check or n < before))
 
 
 def test_oracle_fuse_and_sim3_vs_numpy():
     F = frame(12)
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(SEED0 + 2)
     P = points(F, rng, 1500, 3.0, jitter=3.0)
     g = grid(F)
     for use_chi2 in (1, 0):
@@ -166,7 +170,7 @@ def test_oracle_fuse_and_sim3_vs_numpy():
             if bd <= 50:
                 want[i] = bi
         assert np.array_equal(got, want) and n == (want >= 0).sum() and n > 500
-        assert not use_chi2 or gated > 100
+        assert SEED0 or (not use_chi2 or gated > 100)
     # SearchBySim3: both directions, mutual agreement
     F2 = frame(13)
     g2 = grid(F2)
@@ -217,7 +221,7 @@ def init_case(rng, F2, n1):
 
 def test_oracle_search_for_initialization_vs_numpy():
     F2 = frame(14)
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(SEED0 + 3)
     C = init_case(rng, F2, 1800)
     g2 = grid(F2)
     for check, ratio in ((True, 0.9), (False, 0.8)):
@@ -259,7 +263,7 @@ def test_oracle_search_for_initialization_vs_numpy():
                     for i in hist[bn]:
                         m12[i] = -1
         assert np.array_equal(got, m12) and n == (m12 >= 0).sum() and stolen > 20
-        assert n > 300 and (not check or n < before)
+        assert SEED0 or (n > 300 and (not check or n < before))
         live = got >= 0
         assert np.array_equal(prev_after[live, 0], F2["kx"][got[live]]) and np.array_equal(prev_after[~live], C["prev"][~live])
 
@@ -301,7 +305,7 @@ def shared_nodes(node1, node2):
 
 def test_oracle_search_for_triangulation_vs_numpy():
     F2 = frame(15)
-    rng = np.random.default_rng(4)
+    rng = np.random.default_rng(SEED0 + 4)
     C = tri_case(rng, F2, 1900)
     off1, idx1, off2, idx2 = shared_nodes(C["node1"], C["node2"])
     xy2 = np.stack([F2["kx"], F2["ky"]], 1).astype(np.float32)
@@ -341,7 +345,7 @@ def test_oracle_search_for_triangulation_vs_numpy():
                     dm = d[ok].min()
                     want[a] = int(c[np.nonzero(ok & (d == dm))[0][-1]])          # `dist > bestDist` at :738: the last of equals wins
         assert np.array_equal(got, want) and n == (want >= 0).sum()
-        assert n > (60 if only_stereo else 150) and epi_rejects > 50 and (only_stereo or epipole_rejects > 0)
+        assert SEED0 or (n > (60 if only_stereo else 150) and epi_rejects > 50 and (only_stereo or epipole_rejects > 0))
     # the histogram on top: same as the filter on the unfiltered result
     got0, n0 = O.search_for_triangulation(C["d1"], C["mp1"], C["ur1"], C["xy1"], C["ang1"], F2["d"], C["mp2"], C["ur2"], xy2, F2["oct"],
                                           F2["ang"], off1, idx1, off2, idx2, C["F12"], C["ex"], C["ey"], SF, SIGMA2, 0, 0)
@@ -381,34 +385,34 @@ def run_guided(tmp_path, kind, sides, check_ori=0, third=0, use_gate=0, ratio=0.
 @pytest.mark.gpu
 def test_cpp_sim3_projection_replays_the_reference_loop(tmp_path):
     F = frame(21)
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(SEED0 + 5)
     P = points(F, rng, 2600, 4.0)
     occ = (rng.uniform(size=F["n"]) < 0.1).astype(np.uint8)
     count, rq, match_idx, occ_out = run_guided(tmp_path, 1, [(F, P, occ)])
     want, occ_want, n = O.search_by_projection_sim3(grid(F), P["u"], P["v"], P["radius"], P["level"], P["d"], occ)
     assert np.array_equal(match_idx, want) and count == n and np.array_equal(occ_out, occ_want)
-    assert n > 800 and rq > 10
+    assert SEED0 or (n > 800 and rq > 10)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("orb_dist,check_ori", [(100, 1), (64, 1), (100, 0)])
 def test_cpp_relocalization_projection_replays_the_reference_loop(tmp_path, orb_dist, check_ori):
     F = frame(22)
-    rng = np.random.default_rng(6 + orb_dist)
+    rng = np.random.default_rng(SEED0 + 6 + orb_dist)
     P = points(F, rng, 2400, 10.0 if orb_dist == 100 else 3.0, level_up=(-1, 2))
     occ = (rng.uniform(size=F["n"]) < 0.15).astype(np.uint8)
     count, rq, assigned, occ_out = run_guided(tmp_path, 2, [(F, P, occ)], check_ori=check_ori, third=orb_dist)
     want, occ_want, n = O.search_by_projection_reloc(grid(F), F["ang"], P["u"], P["v"], P["radius"], P["level"], P["ang"], P["d"],
                                                      orb_dist, check_ori, occ)
     assert np.array_equal(assigned, want) and count == n and np.array_equal(occ_out, occ_want)
-    assert n > 700 and rq > 10
+    assert SEED0 or (n > 700 and rq > 10)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_gate", [1, 0])
 def test_cpp_fuse_selection_matches_oracle(tmp_path, use_gate):
     F = frame(23)
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(SEED0 + 7)
     P = points(F, rng, 3000, 3.0, jitter=3.0)
     count, _, best, _ = run_guided(tmp_path, 3, [(F, P, np.zeros(F["n"], np.uint8))], use_gate=use_gate)
     want, n = O.fuse_select(grid(F), INV_SIGMA2, use_gate, P["u"], P["v"], P["ur"], P["radius"], P["level"], P["d"])
@@ -420,7 +424,7 @@ def test_cpp_fuse_selection_matches_oracle(tmp_path, use_gate):
 @pytest.mark.gpu
 def test_cpp_search_by_sim3_matches_oracle(tmp_path):
     F1, F2 = frame(24), frame(25)
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(SEED0 + 8)
     n1, n2 = F1["n"], F2["n"]
     i1 = np.sort(rng.choice(n1, 1000, replace=False)).astype(np.int32)
     t1 = rng.integers(0, n2, len(i1))
@@ -454,7 +458,7 @@ def test_cpp_search_by_sim3_matches_oracle(tmp_path):
 @pytest.mark.parametrize("check_ori,ratio", [(1, 0.9), (0, 0.8)])
 def test_cpp_search_for_initialization_replays_the_reference_loop(tmp_path, check_ori, ratio):
     F2 = frame(26)
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(SEED0 + 9)
     C = init_case(rng, F2, 1800)
     lvl0 = np.nonzero(C["oct1"] == 0)[0].astype(np.int32)              # the adapter is handed the level-0 keypoints (:421-423)
     P = dict(u=C["prev"][lvl0, 0].copy(), v=C["prev"][lvl0, 1].copy(), ur=np.zeros(len(lvl0), np.float32),
@@ -463,14 +467,14 @@ def test_cpp_search_for_initialization_replays_the_reference_loop(tmp_path, chec
     count, rq, m12, _ = run_guided(tmp_path, 5, [(F2, P, np.zeros(F2["n"], np.uint8))], check_ori=check_ori, third=C["n1"], ratio=ratio)
     want, _, n = O.search_for_initialization(grid(F2), F2["ang"], C["oct1"], C["ang1"], C["d1"], C["prev"], 100, ratio, check_ori)
     assert np.array_equal(m12, want) and count == n
-    assert n > 300 and rq > 10                                          # contention for F2 keypoints occurred and was replayed
+    assert SEED0 or (n > 300 and rq > 10)                                          # contention for F2 keypoints occurred and was replayed
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("only_stereo,check_ori", [(0, 1), (1, 1), (0, 0)])
 def test_cpp_search_for_triangulation_matches_oracle(tmp_path, only_stereo, check_ori):
     F2 = frame(27)
-    rng = np.random.default_rng(10)
+    rng = np.random.default_rng(SEED0 + 10)
     C = tri_case(rng, F2, 1900)
     n1, n2 = C["n1"], F2["n"]
     ent1 = np.stack([C["node1"], np.arange(n1)], 1).astype(np.int32)
@@ -496,7 +500,7 @@ def test_cpp_search_for_triangulation_matches_oracle(tmp_path, only_stereo, chec
                                          F2["ang"], off1, idx1, off2, idx2, C["F12"], C["ex"], C["ey"], SF, SIGMA2, only_stereo, check_ori)
     live = np.nonzero(want >= 0)[0]
     assert nmatches == n == npairs and np.array_equal(pairs[:, 0], live) and np.array_equal(pairs[:, 1], want[live])
-    assert n > (60 if only_stereo else 150)
+    assert SEED0 or (n > (60 if only_stereo else 150))
 
 
 @pytest.mark.gpu
@@ -505,7 +509,7 @@ def test_search_area_ex_options_match_oracle():
     loops; bad arguments are refused."""
     from orb_slam2_amd import capi
     F = frame(28)
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(SEED0 + 12)
     P = points(F, rng, 800, 3.0, jitter=3.0)
     m = capi.ORBmatcher(device=0)
     fg = capi.FrameGrid(F["kx"], F["ky"], F["oct"], F["d"], F["ur"], 0.0, 0.0, float(W_INV), float(H_INV))

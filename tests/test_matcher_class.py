@@ -19,6 +19,10 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+# ORBFE_CLASS_SEED shifts every generator seed of this file: the default suite runs seed 0, a soak (tools/class_soak.sh)
+# runs others; the "this case is not vacuous" counts are tuned for seed 0 and only asserted there (`assert SEED0 or ...`)
+SEED0 = 1000003 * int(os.environ.get("ORBFE_CLASS_SEED", "0"))
+
 ROOT = Path(__file__).resolve().parent.parent
 CPP_BIN = Path(os.environ.get("ORBFE_TEST_BIN_DIR", ROOT / "tests" / "cpp"))   # tools/run_asan.sh points this at tests/cpp/_asan
 sys.path.insert(0, str(ROOT))
@@ -234,7 +238,7 @@ def rot_bin(a1, a2):
 def test_search_local_points(tmp_path, th):
     """src/ORBmatcher.cc:45-129 as Tracking::SearchLocalPoints calls it (src/Tracking.cc:1185-1192): the MapPoints carry the
     projection Frame::isInFrustum left in them."""
-    rng = np.random.default_rng(100)
+    rng = np.random.default_rng(SEED0 + 100)
     V = view(41, pose(rng), 7)
     n = V["n"]
     nq = 2600
@@ -278,7 +282,7 @@ def test_search_local_points(tmp_path, th):
         slot[res[1]] = k
         want_n += 1
     assert np.array_equal(got, slot) and nmatches == want_n
-    assert want_n > 500 and (slot != V["mp"]).sum() > 500
+    assert SEED0 or (want_n > 500 and (slot != V["mp"]).sum() > 500)
 
 
 # ------------------------------------------------------------------ 2. SearchByProjection(CurrentFrame, LastFrame) -------
@@ -286,7 +290,7 @@ def test_search_local_points(tmp_path, th):
 def test_track_with_motion_model(tmp_path, mode, check_ori):
     """src/ORBmatcher.cc:1328-1470 as Tracking::TrackWithMotionModel calls it (src/Tracking.cc:886-892): projection of the
     last frame's MapPoints with the current pose, level window by the motion direction, right-coordinate gate, histogram."""
-    rng = np.random.default_rng(200 + len(mode))
+    rng = np.random.default_rng(SEED0 + 200 + len(mode))
     Tc = pose(rng)
     Tl = Tc.copy()
     dz = {"forward": 1.5, "backward": -1.5, "still": 0.1, "mono": 1.5}[mode]
@@ -354,14 +358,14 @@ def test_track_with_motion_model(tmp_path, mode, check_ori):
                     slot[b] = -1
                     nm -= 1
     assert np.array_equal(got, slot) and nmatches == nm
-    assert nm > 600 and overwritten > 0
+    assert SEED0 or (nm > 600 and overwritten > 0)
 
 
 # ------------------------------------------------------------------ 3. SearchByProjection(CurrentFrame, KeyFrame*, ...) ---
 @pytest.mark.parametrize("orb_dist,th,check_ori", [(100, 10.0, 1), (64, 3.0, 1), (100, 10.0, 0)])
 def test_relocalization_projection(tmp_path, orb_dist, th, check_ori):
     """src/ORBmatcher.cc:1472-1599 as Tracking::Relocalization calls it (src/Tracking.cc:1453, :1467)."""
-    rng = np.random.default_rng(300 + orb_dist)
+    rng = np.random.default_rng(SEED0 + 300 + orb_dist)
     Tc = pose(rng)
     Cur, KF = view(44, Tc, 21), view(45, pose(rng), 20)
     n, nk = Cur["n"], KF["n"]
@@ -397,13 +401,13 @@ def test_relocalization_projection(tmp_path, orb_dist, th, check_ori):
     want[first >= 0] = -1                                                      # every keypoint the loop wrote ...
     want[assigned >= 0] = q[assigned[assigned >= 0]]                           # ... keeps its point only if the histogram kept it
     assert np.array_equal(got, want) and nmatches == n_want
-    assert n_want > 500 and (not check_ori or (first >= 0).sum() > n_want)
+    assert SEED0 or (n_want > 500 and (not check_ori or (first >= 0).sum() > n_want))
 
 
 # ------------------------------------------------------------------ 4. SearchByProjection(KeyFrame*, Scw, ...) ------------
 def test_sim3_projection(tmp_path):
     """src/ORBmatcher.cc:290-403 as LoopClosing::ComputeSim3 calls it (src/LoopClosing.cc:375)."""
-    rng = np.random.default_rng(400)
+    rng = np.random.default_rng(SEED0 + 400)
     T = pose(rng)
     s = 1.07
     Scw = T.copy()
@@ -436,7 +440,7 @@ def test_sim3_projection(tmp_path):
     want = matched_in.copy()
     want[m_idx[m_idx >= 0]] = lst[q[m_idx >= 0]]
     assert np.array_equal(got, want) and nmatches == n_want
-    assert n_want > 700 and (~live).sum() > 300                                # the gates removed something too
+    assert SEED0 or (n_want > 700 and (~live).sum() > 300)                                # the gates removed something too
 
 
 # ------------------------------------------------------------------ 5 / 6. SearchByBoW ------------------------------------
@@ -459,7 +463,7 @@ def bow_views(rng):
 @pytest.mark.parametrize("check_ori", [1, 0])
 def test_search_by_bow_keyframe_frame(tmp_path, check_ori):
     """src/ORBmatcher.cc:159-288 (Tracking::TrackReferenceKeyFrame, src/Tracking.cc:765-768)."""
-    rng = np.random.default_rng(500)
+    rng = np.random.default_rng(SEED0 + 500)
     V1, V2 = bow_views(rng)
     n1, n2 = V1["n"], V2["n"]
     P = points_seen_from(V1, rng, np.arange(n1))
@@ -477,13 +481,13 @@ def test_search_by_bow_keyframe_frame(tmp_path, check_ori):
     want = np.full(n2, -1, np.int32)
     want[ref[ref >= 0]] = np.nonzero(ref >= 0)[0]                              # vpMapPointMatches[idxF] = MapPoint of KF feature
     assert size == n2 and np.array_equal(got, want) and nmatches == n_ref
-    assert n_ref > 300 and (not check_ori or n_ref < before)
+    assert SEED0 or (n_ref > 300 and (not check_ori or n_ref < before))
 
 
 @pytest.mark.parametrize("check_ori", [1, 0])
 def test_search_by_bow_keyframe_keyframe(tmp_path, check_ori):
     """src/ORBmatcher.cc:522-655 (LoopClosing::ComputeSim3, src/LoopClosing.cc:265): strict '<' TH_LOW, side 2 needs a good point."""
-    rng = np.random.default_rng(600)
+    rng = np.random.default_rng(SEED0 + 600)
     V1, V2 = bow_views(rng)
     n1, n2 = V1["n"], V2["n"]
     P1, P2 = points_seen_from(V1, rng, np.arange(n1)), points_seen_from(V2, rng, np.arange(n2))
@@ -503,14 +507,14 @@ def test_search_by_bow_keyframe_keyframe(tmp_path, check_ori):
         ref, n_ref = O.rotation_filter(V1["ang"], V2["ang"], ref)
     want = np.where(ref >= 0, n1 + ref, -1).astype(np.int32)                   # vpMatches12[idx1] = MapPoint of KF2 feature
     assert size == n1 and np.array_equal(got, want) and nmatches == n_ref
-    assert n_ref > 300 and (not check_ori or n_ref < before)
+    assert SEED0 or (n_ref > 300 and (not check_ori or n_ref < before))
 
 
 # ------------------------------------------------------------------ 7. SearchForInitialization ---------------------------
 @pytest.mark.parametrize("check_ori,ratio", [(1, 0.9), (0, 0.8)])
 def test_search_for_initialization(tmp_path, check_ori, ratio):
     """src/ORBmatcher.cc:405-520 (Tracking::MonocularInitialization, src/Tracking.cc:600-601)."""
-    rng = np.random.default_rng(700)
+    rng = np.random.default_rng(SEED0 + 700)
     F2 = view(50, pose(rng), 51)
     n2 = F2["n"]
     F1 = view(49, pose(rng), 50)
@@ -529,7 +533,7 @@ def test_search_for_initialization(tmp_path, check_ori, ratio):
     want, prev_want, n_want = O.search_for_initialization(grid_of(F2, False), F2["ang"], F1["oct"], F1["ang"], F1["d"], prev, 100, ratio,
                                                           check_ori)
     assert np.array_equal(got, want) and nmatches == n_want and np.array_equal(prev_after, prev_want)
-    assert n_want > 300
+    assert SEED0 or (n_want > 300)
 
 
 # ------------------------------------------------------------------ 8. SearchForTriangulation ----------------------------
@@ -537,7 +541,7 @@ def test_search_for_initialization(tmp_path, check_ori, ratio):
 def test_search_for_triangulation(tmp_path, only_stereo, check_ori):
     """src/ORBmatcher.cc:657-823 (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:268): the epipole comes from the two
     keyframe poses (:664-670)."""
-    rng = np.random.default_rng(800)
+    rng = np.random.default_rng(SEED0 + 800)
     n2 = frame(52)["n"]
     node2 = rng.integers(0, 90, n2) * 3
     K2 = view(52, np.eye(4, dtype=f32), 61, nodes=node2)
@@ -584,14 +588,14 @@ def test_search_for_triangulation(tmp_path, only_stereo, check_ori):
                                               only_stereo, check_ori)
     live = np.nonzero(want >= 0)[0]
     assert nmatches == n_want == npairs and np.array_equal(pairs[:, 0], live) and np.array_equal(pairs[:, 1], want[live])
-    assert n_want > (30 if only_stereo else 120)
-    assert 0 < ex < 1241 and 0 < ey < 376 and near2.sum() > 3
+    assert SEED0 or (n_want > (30 if only_stereo else 120))
+    assert SEED0 or (0 < ex < 1241 and 0 < ey < 376 and near2.sum() > 3)
 
 
 # ------------------------------------------------------------------ 9. SearchBySim3 --------------------------------------
 def test_search_by_sim3(tmp_path):
     """src/ORBmatcher.cc:1102-1326 (LoopClosing::ComputeSim3, src/LoopClosing.cc:323)."""
-    rng = np.random.default_rng(900)
+    rng = np.random.default_rng(SEED0 + 900)
     T1, T2 = pose(rng), pose(rng)
     K1, K2 = view(53, T1, 70), view(54, T2, 71)
     n1, n2 = K1["n"], K2["n"]
@@ -654,7 +658,7 @@ def test_search_by_sim3(tmp_path):
     want = in12.copy()
     want[m12 >= 0] = K2["mp"][m12[m12 >= 0]]
     assert np.array_equal(got, want) and n_found == n_want
-    assert 150 < n_want < len(i1)
+    assert SEED0 or (150 < n_want < len(i1))
 
 
 # ------------------------------------------------------------------ 10. Fuse(KeyFrame*, vpMapPoints, th) ------------------
@@ -662,7 +666,7 @@ def test_fuse_into_keyframe(tmp_path):
     """src/ORBmatcher.cc:825-975 (LocalMapping::SearchInNeighbors, src/LocalMapping.cc:489, :514): selection with the
     reprojection gate, then Replace / AddObservation in the loop's order -- points listed twice, points that an earlier
     fusion of the same call turned bad or put into the keyframe."""
-    rng = np.random.default_rng(1000)
+    rng = np.random.default_rng(SEED0 + 1000)
     T = pose(rng)
     KF, Other = view(55, T, 80), view(56, pose(rng), 81)
     n = KF["n"]
@@ -759,13 +763,13 @@ def test_fuse_into_keyframe(tmp_path):
     assert np.array_equal(got_slots, slots[0])
     assert np.array_equal(state[:, 0], bad) and np.array_equal(state[:, 1], nobs) and np.array_equal(state[:, 2], replaced)
     assert np.array_equal(state[:, 3], np.array([o.get(0, -1) for o in obs], np.int32))
-    assert replaced_n > 200 and added_n > 200 and closed_n > 20
+    assert SEED0 or (replaced_n > 200 and added_n > 200 and closed_n > 20)
 
 
 # ------------------------------------------------------------------ 11. Fuse(KeyFrame*, Scw, ...) -------------------------
 def test_fuse_with_sim3(tmp_path):
     """src/ORBmatcher.cc:977-1100 (LoopClosing::SearchAndFuse, src/LoopClosing.cc:600)."""
-    rng = np.random.default_rng(1100)
+    rng = np.random.default_rng(SEED0 + 1100)
     T = pose(rng)
     s = 0.94
     Scw = T.copy()
@@ -815,13 +819,13 @@ def test_fuse_with_sim3(tmp_path):
             slots[best[a]] = lst[k]                                            # AddMapPoint: a later point finds it there
         want_fused += 1
     assert n_fused == want_fused and np.array_equal(got_replace, want_replace) and np.array_equal(got_slots, slots)
-    assert want_fused > 800 and (want_replace >= 0).sum() > 200 and (slots != KF["mp"]).sum() > 200
+    assert SEED0 or (want_fused > 800 and (want_replace >= 0).sum() > 200 and (slots != KF["mp"]).sum() > 200)
 
 
 def test_constants_and_descriptor_distance(tmp_path):
     """TH_LOW / TH_HIGH / HISTO_LENGTH (src/ORBmatcher.cc:37-39; read by src/Frame.cc:471, :522) and the static
     DescriptorDistance (:1647-1663; called from src/Frame.cc:541 and src/MapPoint.cc:281)."""
-    rng = np.random.default_rng(1200)
+    rng = np.random.default_rng(SEED0 + 1200)
     V = view(41, pose(rng), 1)
     P = points_seen_from(V, rng, np.arange(1))
     out = run(tmp_path, 12, [V], P, [1], [0.6, 0])
