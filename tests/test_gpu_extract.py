@@ -367,6 +367,38 @@ def test_queued_batches_of_changing_frame_count_and_image_size():
             assert np.array_equal(dh[f, :n[f]], dr), (F, w, h, f)
 
 
+def test_record_of_queued_batches_is_bounded():
+    """A caller that queues asynchronous batches and never synchronises: the library keeps a record of every queued call
+    (for the overflow rerun) and synchronises by itself every 4096 calls, so the record cannot grow without bound.  4200
+    one-frame batches into four rotating output slots; the last four equal the oracle."""
+    torch = pytest.importorskip("torch")
+    w, h, cap = 320, 240, 300
+    o = O.OracleExtractor(200, 1.2, 4, 20, 7)
+    g = capi.ORBextractor(200, 1.2, 4, 20, 7)
+    stride = (w + 63) // 64 * 64
+    host = np.zeros((4, h, stride), np.uint8)
+    for f in range(4):
+        host[f, :, :w] = synth.textured_image(w, h, synth.BASE_SEED + 900 + f)
+    frames = torch.from_numpy(host).cuda()
+    kps = torch.zeros((4, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((4, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(4200):
+        s = k & 3
+        g.extract_batch_device(frames[s].data_ptr(), 1, w, h, stride, stride * h, kps[s].data_ptr(), desc[s].data_ptr(),
+                               cnt[s:].data_ptr(), cap, sync=False)
+    g.synchronize()
+    n = cnt.cpu().numpy()
+    kh = kps.cpu().numpy().view(np.uint8).reshape(4, cap, 28)
+    dh = desc.cpu().numpy()
+    for f in range(4):
+        kr, dr = o.extract(np.ascontiguousarray(host[f, :, :w]))
+        assert n[f] == len(kr) and len(kr) > 50
+        assert np.array_equal(kh[f, :n[f]].copy().view(capi.KP_DTYPE).reshape(-1), kr)
+        assert np.array_equal(dh[f, :n[f]], dr)
+
+
 @pytest.mark.parametrize("w,h,scale,nlevels", [(1434, 605, 2.0, 4), (1245, 574, 2.0, 3), (1400, 1000, 3.0, 3), (1300, 900, 2.5, 3)])
 def test_resize_ratios_outside_the_register_windows(w, h, scale, nlevels):
     """Level sizes are rounded, so a scale factor of 2 can give a level ratio slightly above 2 (1434 -> 717 -> 358); those
