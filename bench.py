@@ -715,6 +715,13 @@ def main():
                                     "references + the sample pre-pass and the folds; the best/second selection runs only where a "
                                     "reference can still matter (sample-seeded threshold)"}}
 
+        if sharded is not None:
+            # the library's RCCL communicator goes before torch's process group does: every rank has passed the barrier of the
+            # last htime() and drained its stream
+            barrier()
+            sharded.close()
+            sharded = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(uniq)
