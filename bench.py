@@ -573,6 +573,17 @@ def main():
     roofline["stage_hbm"] = {k: {"algorithmic_GBps": round(stage_bytes[k] * spf / (stages[k] * 1e-3) / 1e9, 1),
                                  "frac_of_8TBps": round(stage_bytes[k] * spf / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                              for k in stage_bytes if stages.get(k, 0) > 0}
+    # the same stages by the HBM bytes the PMC passes counted (FETCH_SIZE x 2 + WRITE_SIZE, per launch of 512 frames in
+    # profiles/latest_pmc.json; the pyramid is nlevels - 1 launches), against this run's stage times
+    stage_kernel = {"pyramid": ("pyr_resize_kernel", NLEVELS - 1), "fast": ("fast_cells_kernel", 1), "blur": ("gauss7_kernel", 1),
+                    "describe": ("orient_describe_kernel", 1), "quadtree": ("quadtree_kernel", 1)}
+    for k, (kn, nl) in stage_kernel.items():
+        c = (pmc or {}).get("kernels", {}).get(kn, {})
+        if k in roofline["stage_hbm"] and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            per_frame = nl * (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / pmc_frames
+            gbs = per_frame * spf / (stages[k] * 1e-3) / 1e9
+            roofline["stage_hbm"][k].update({"pmc_bytes_per_frame": int(per_frame), "pmc_traffic_GBps": round(gbs, 1),
+                                             "pmc_frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4)})
 
     # ---- Hamming kNN-2: 2000 queries vs a 1M database sharded over the ranks, RCCL gather of per-shard results
     hamming = None
