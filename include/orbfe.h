@@ -92,7 +92,8 @@ int orbfe_extract(orbfe_extractor *e, const uint8_t *img, int w, int h, int stri
  * returns.  Any number of batches may be queued; if a frame of one of them overflows the running FAST kernel's per-strip
  * survivor list (dense noise -- the reference's std::vector just grows, src/ORBextractor.cc:779), orbfe_synchronize runs ALL
  * batches queued since the last synchronisation again, in order, with the large-list kernel, so the outputs are the
- * reference's whatever the content.  The handle returns to the normal kernel by itself after a number of batches. */
+ * reference's whatever the content.  The handle returns to the normal kernel by itself after a number of batches.  After 4096
+ * queued calls the library synchronises by itself (same status handling), so its record of them stays bounded. */
 int orbfe_extract_batch(orbfe_extractor *e, const uint8_t *dev_imgs, int n_frames, int w, int h, int stride,
                         size_t frame_stride, orbfe_keypoint *dev_kps, uint8_t *dev_desc, int32_t *dev_counts, int cap,
                         int sync);
