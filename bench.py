@@ -711,6 +711,9 @@ def main():
                    "back_to_back": None if hdt_b2b is None else {"pairs_per_s": round(pairs / hdt_b2b, 1),
                                                                  "ms_per_query_batch": round(hdt_b2b / hsteps * 1e3, 3),
                                                                  "batches_queued": 4 * hsteps},
+                   # "matches/sec" of BASELINE.json's metric: queries matched (best + second-best over the whole database, the
+                   # input of the ratio test) per second, in the faster of the two modes
+                   "matches_per_s": round(NQ * hsteps / min(hdt, hdt_b2b or hdt), 1),
                    "exchange": "none (one shard)" if world == 1 else ("RCCL inside liborbfe (orbfe_knn2_sharded_run)" if sharded is not None
                                                                       else "host collectives (rehearsal backend) + orbfe_merge_knn2"),
                    "valu": {"achieved_Tpairs": round(best / 1e12, 3),
