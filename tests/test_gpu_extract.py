@@ -211,7 +211,10 @@ def _fuzz_image(rng, w, h, kind, seed):
     return np.ascontiguousarray(img)
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("ORBFE_FUZZ_CASES", "40"))))
+_FUZZ_FIRST = int(os.environ.get("ORBFE_FUZZ_FIRST", "0"))     # a soak continues where the last one stopped
+
+
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("ORBFE_FUZZ_CASES", "40"))))
 def test_fuzz_configurations(case):
     """Seeded random configurations (size, quota, scale factor, level count, thresholds, image statistics), every stage
     bit-exact against the oracle.  Configurations the reference itself cannot run (a level smaller than one FAST cell,
@@ -233,6 +236,55 @@ def test_fuzz_configurations(case):
         _stage_check(img, nfeatures, scale, nlevels, ini_th, min_th)
     except AssertionError as e:
         raise AssertionError(f"config {cfg}: {e}") from e
+
+
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(1, int(os.environ.get("ORBFE_FUZZ_CASES", "40")) // 5)))
+def test_fuzz_queued_batches(case):
+    """The batch entry point under the same random configurations: one to four asynchronous batches of one to six frames of
+    mixed statistics (noise frames among ordinary ones: the overflow rerun of queued batches; `cap` sometimes below the
+    keypoint count: truncated outputs, full counts), one synchronisation, every frame equal to the oracle."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(19000 + case)
+    scale = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0]))
+    nlevels = int(rng.integers(1, 9))
+    w = int(rng.integers(224, 1300))
+    h = int(rng.integers(224, min(w, 800) + 1))
+    while nlevels > 1 and min(w, h) / scale ** (nlevels - 1) < 72:
+        nlevels -= 1
+    nfeatures = int(rng.choice([30, 300, 1000, 2000]))
+    ini_th = int(rng.integers(8, 45))
+    min_th = int(rng.integers(2, ini_th + 1))
+    o = O.OracleExtractor(nfeatures, scale, nlevels, ini_th, min_th)
+    g = capi.ORBextractor(nfeatures, scale, nlevels, ini_th, min_th)
+    stride = (w + 63) // 64 * 64
+    cap = int(nfeatures * float(rng.choice([0.5, 1.1, 1.1, 2.0]))) + 4 * nlevels + 8
+    held = []
+    for b in range(int(rng.integers(1, 5))):
+        F = int(rng.integers(1, 7))
+        host = np.zeros((F, h, stride), np.uint8)
+        for f in range(F):
+            kind = str(rng.choice(["textured", "textured", "textured", "low_contrast", "flat_regions", "saturated", "noise"]))
+            host[f, :, :w] = _fuzz_image(rng, w, h, kind, 30000 + 64 * case + 8 * b + f)
+        frames = torch.from_numpy(host).cuda()
+        kps = torch.zeros((F, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros((F,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g.extract_batch_device(frames.data_ptr(), F, w, h, stride, stride * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
+                               cap, sync=False)
+        held.append((host, frames, kps, desc, cnt))
+    g.synchronize()
+    cfg = (case, w, h, nfeatures, scale, nlevels, ini_th, min_th, cap)
+    for b, (host, _frames, kps, desc, cnt) in enumerate(held):
+        n = cnt.cpu().numpy()
+        kh = kps.cpu().numpy().view(np.uint8).reshape(len(host), cap, 28)
+        dh = desc.cpu().numpy()
+        for f in range(len(host)):
+            kr, dr = o.extract(np.ascontiguousarray(host[f, :, :w]))
+            assert n[f] == len(kr), (cfg, b, f)
+            m = min(len(kr), cap)
+            assert np.array_equal(kh[f, :m].copy().view(capi.KP_DTYPE).reshape(-1), kr[:m]), (cfg, b, f)
+            assert np.array_equal(dh[f, :m], dr[:m]), (cfg, b, f)
 
 
 def test_dense_noise_switches_to_the_large_survivor_list():

@@ -8,6 +8,7 @@ import oracle_lib as O
 from orb_slam2_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
+_FUZZ_FIRST = int(os.environ.get("ORBFE_FUZZ_FIRST", "0"))     # a soak continues where the last one stopped
 torch = pytest.importorskip("torch")
 
 
@@ -37,7 +38,7 @@ def test_knn2_matches_oracle(nq, nr):
         assert np.array_equal(g, r), name
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("ORBFE_MATCH_FUZZ_CASES", "12"))))
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("ORBFE_MATCH_FUZZ_CASES", "12"))))
 def test_knn2_fuzz(case):
     """Seeded random shapes on both sides of the seeded-scan threshold (32 768 references), with descriptor statistics that
     force ties: a small alphabet of rows (many equal distances, duplicates everywhere), sparse rows (few set bits, distances
@@ -467,7 +468,7 @@ def test_search_by_bow_matches_oracle(n1, n2, nn):
     assert total > 20
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("ORBFE_MATCH_FUZZ_CASES", "12"))))
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("ORBFE_MATCH_FUZZ_CASES", "12"))))
 def test_matcher_fuzz(case):
     """Seeded random shapes for the other matching entry points, in turn: SearchByBoW node lists, candidate-list argmin,
     DBoW2 descent over random trees, and the full stereo matcher on a random pair of random size.  Bit-exact against the
