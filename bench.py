@@ -125,6 +125,22 @@ def cpu_baseline(frames: np.ndarray, budget_s: float = 12.0) -> dict:
                       f"oracle built -O3 -march=x86-64-v3 -ffp-contract=off; {kps / n:.0f} keypoints/frame"}
 
 
+def plan_rank(total_frames: int, world: int, rank: int, batch: int):
+    """(first frame, frames per step, frames per launch) of one rank.  total_frames > 0 (strong scaling): contiguous blocks of
+    ceil(total / G) frames, the last ranks may get fewer or none; 0 (weak): `batch` frames per rank.  The block is cut into
+    EQUAL orbfe_extract_batch launches of at most `batch` frames (4541 -> 8 x 568, 568 -> 1 x 568), never a full launch plus
+    a small ragged one (512 + 56 ran the tail at the 64-frame rate)."""
+    if total_frames > 0:
+        block = -(-total_frames // world)
+        f_first = min(rank * block, total_frames)
+        B = max(min(block, total_frames - f_first), 0)
+    else:
+        f_first, B = rank * batch, batch
+    n_launches = max(1, -(-max(B, 1) // max(batch, 1)))
+    launch = max(1, -(-max(B, 1) // n_launches))
+    return f_first, B, launch
+
+
 def csrc_hash() -> str:
     """sha256 over the sources of liborbfe.so in name order (the same rule as tools/pmc_latest.py)"""
     import hashlib
@@ -451,16 +467,7 @@ def main():
 
     # ---- synthetic frames, resident in HBM before anything is timed
     strong = args.total_frames > 0
-    if strong:
-        block = -(-args.total_frames // world)                       # contiguous blocks of ceil(total / G) frames
-        f_first = min(rank * block, args.total_frames)
-        B = max(min(block, args.total_frames - f_first), 0)          # this rank's frames per step
-    else:
-        f_first, B = rank * args.batch, args.batch
-    # frames per orbfe_extract_batch call: the block in equal launches (4541 -> 8 x 568, 568 -> 1 x 568), never a full launch
-    # plus a small ragged one (512 + 56 ran the tail at the 64-frame rate)
-    n_launches = max(1, -(-max(B, 1) // max(args.batch, 1)))
-    launch = max(1, -(-max(B, 1) // n_launches))
+    f_first, B, launch = plan_rank(args.total_frames, world, rank, args.batch)
     stride = (W + 63) // 64 * 64
     uniq = synth.frame_sequence(N_UNIQUE, W, H, first=0)
     uniq_dev = torch.zeros((N_UNIQUE, H, stride), dtype=torch.uint8)

@@ -66,3 +66,25 @@ def test_sharded_knn2_gloo_world2(tmp_path):
     out = tmp_path / "ok.txt"
     mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
     assert out.read_text() == "1"
+
+
+def test_bench_frame_plan_covers_the_sequence_once():
+    """bench.py's split of the 4541-frame step (BASELINE.json configs[3]) over 1 / 2 / 4 / 8 ranks and further counts: contiguous
+    blocks that cover every frame exactly once, equal launches of at most --batch frames, no small ragged tail launch."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    for total in (4541, 1, 7, 640, 641, 5000):
+        for world in (1, 2, 3, 4, 8, 16):
+            nxt = 0
+            for rank in range(world):
+                first, B, launch = bench.plan_rank(total, world, rank, 640)
+                assert first == min(nxt, total) and 0 <= B and 1 <= launch <= 640
+                nxt = first + B
+                if B:
+                    sizes = [min(launch, B - f0) for f0 in range(0, B, launch)]
+                    assert sum(sizes) == B and len(sizes) == -(-B // 640)          # as few launches as the cap allows
+                    assert max(sizes) - min(sizes) < len(sizes)                    # equal up to the rounding of the division
+            assert nxt == total
+    assert bench.plan_rank(4541, 1, 0, 640) == (0, 4541, 568)
+    assert bench.plan_rank(4541, 8, 7, 640) == (3976, 565, 565)
+    assert bench.plan_rank(0, 4, 2, 512) == (1024, 512, 512)                       # weak scaling: --batch frames per rank
